@@ -1,0 +1,161 @@
+/* xm3d.h - C ABI of libxm3d_hip.so: the MI355X (gfx950) hot path of XMask3D.
+ *
+ * Plain pointers and sizes only; no torch types.  Every pointer is a DEVICE
+ * pointer unless the comment says HOST.  `stream` is a hipStream_t passed as
+ * void* (NULL = the null stream).  All entry points return 0 on success or a
+ * negative XM3D_E* code; xm3d_last_error() gives the message (thread local).
+ * Kernels are enqueued on `stream`; only the entry points documented as
+ * "syncs" wait for the device (they return a count the caller needs on the
+ * host to size the next allocation - the reference returns arrays of that
+ * length at the same point, so the sync is inherent in its interface too).
+ *
+ * Each entry point names the reference interface it replaces (file:line under
+ * the upstream XMask3D tree).
+ */
+#ifndef XM3D_H
+#define XM3D_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define XM3D_OK 0
+#define XM3D_EINVAL -1   /* bad argument (shape, alignment, range)          */
+#define XM3D_EHIP -2     /* HIP runtime error                              */
+#define XM3D_ENOSPC -3   /* workspace too small / hash table overflow      */
+#define XM3D_ERANGE -4   /* coordinate outside the packable range          */
+
+const char* xm3d_last_error(void);
+int xm3d_version(void);
+/* Fills HOST ints: number of CUs, wavefront size, and gcnArchName (<=63 chars) of device `dev`. */
+int xm3d_device_info(int dev, int* n_cu, int* wave, char* arch64);
+
+/* ---------------------------------------------------------------------------
+ * Voxelisation  (replaces dataset/voxelizer.py:81-132 Voxelizer.voxelize and
+ * dataset/voxelization_utils.py:6-18,38-102 fnv_hash_vec / sparse_quantize)
+ *
+ * xyz      (n,3) f64 metres
+ * T16      HOST 16 doubles, row-major 4x4 rigid transform (M_r @ M_v)
+ * grid     (n,3) i32 out: first n_unique rows = integer voxel coords (min-shifted),
+ *                 in ascending-FNV-key order (== reference `locs`)
+ * inds     (n)   i64 out: first n_unique = index of first point of each voxel
+ * inverse  (n)   i64 out: voxel row of every point (== inds_reconstruct)
+ * n_unique HOST  i64 out.                                      SYNCS `stream`.
+ * ws/ws_bytes    scratch; query the size with xm3d_voxelize_ws_bytes(n).
+ * ------------------------------------------------------------------------- */
+int xm3d_voxelize_ws_bytes(int64_t n, size_t* bytes);
+int xm3d_voxelize(const double* xyz, int64_t n, const double* T16, int32_t* grid, int64_t* inds,
+                  int64_t* inverse, int64_t* n_unique, void* ws, size_t ws_bytes, void* stream);
+/* FNV keys only (known-answer tests): grid (n,3) i32 -> keys (n) u64. */
+int xm3d_fnv_keys(const int32_t* grid, int64_t n, uint64_t* keys, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Coordinate manager primitives (replace MinkowskiEngine's coordinate manager,
+ * reached from run/train.py:483, run/infer.py:462 `SparseTensor(feats, coords)`
+ * and implicitly from every ME.MinkowskiConvolution in
+ * models/modeling/meta_arch/mink_unet.py:47-109).
+ *
+ * Coordinates are (n,4) i32 rows [batch, x, y, z]; packable range is
+ * 0 <= batch < 32768, -32768 <= x,y,z < 32768 (XM3D_ERANGE otherwise; checked
+ * on device, reported by the next syncing call or xm3d_check_flag()).
+ * ------------------------------------------------------------------------- */
+/* Strided coordinate set: out = unique(floor(c/ts_out)*ts_out), ascending (b,x,y,z).
+ * out_coords must hold n rows; *n_out HOST.  SYNCS.  ws from xm3d_stride_ws_bytes. */
+int xm3d_stride_ws_bytes(int64_t n, size_t* bytes);
+int xm3d_coords_stride(const int32_t* coords, int64_t n, int32_t ts_out, int32_t* out_coords,
+                       int64_t* n_out, void* ws, size_t ws_bytes, void* stream);
+/* Spatially sorted processing order of a coordinate set: order[i] = row index of the
+ * i-th coordinate in ascending (b,x,y,z).  Also reports duplicates: *n_unique HOST (SYNCS). */
+int xm3d_coords_order(const int32_t* coords, int64_t n, int32_t* order, int64_t* n_unique,
+                      void* ws, size_t ws_bytes, void* stream);
+/* Open-addressing hash coords->row.  cap must be a power of two >= 2n.
+ * table_keys (cap) u64, table_vals (cap) i32: filled by this call. */
+int xm3d_hash_build(const int32_t* coords, int64_t n, uint64_t* table_keys, int32_t* table_vals,
+                    int64_t cap, void* stream);
+/* Neighbour table ("rulebook", output-stationary form): for every output row o and
+ * kernel offset k (x fastest; odd k centred, even k in {0..k-1}; scaled by `ts`):
+ *   nbr[k*n_out + o] = row of the hashed set at out_coords[o] + sign*offset_k, or -1.
+ * sign=+1: stride-1 and strided convs (hash = input set);
+ * sign=-1: transposed conv (hash = coarse input set, out_coords = fine set). */
+int xm3d_kernel_map(const int32_t* out_coords, int64_t n_out, const uint64_t* table_keys,
+                    const int32_t* table_vals, int64_t cap, int32_t ksize, int32_t ts, int32_t sign,
+                    int32_t* nbr, void* stream);
+/* Reads and clears the device error flag (SYNCS the device). 0 or XM3D_ERANGE/XM3D_ENOSPC. */
+int xm3d_check_flag(void);
+
+/* ---------------------------------------------------------------------------
+ * Sparse convolution (replaces ME.MinkowskiConvolution / ConvolutionTranspose
+ * forward+backward, mink_unet.py:47-109, resnet_base.py:68, and the fused
+ * MinkowskiBatchNorm(eval)+MinkowskiReLU+residual epilogue of BasicBlock).
+ *
+ *   out[o,:] = epi( sum_k  in[nbr[k,o],:] @ W[k] )           W: (K,Cin,Cout) f32
+ *   epi(v)   = relu?( v*scale + shift + residual[o,:] )      (each part optional)
+ *
+ * order (n_out) i32 or NULL: processing order of output rows (locality only,
+ * never changes results).  algo: 0 = auto, 1 = scalar reference kernel (W as
+ * given), 2 = MFMA f32 kernel: W must then be the fragment-ordered buffer made
+ * by xm3d_spconv_pack_weight and Cin, Cout multiples of 32 (the 3-channel stem
+ * runs on algo 1).  nbr may be NULL for K=1 (identity map, plain GEMM).
+ * ------------------------------------------------------------------------- */
+int xm3d_spconv_fwd(const float* in, int64_t n_in, int32_t cin, const float* W, int32_t K, int32_t cout,
+                    const int32_t* nbr, const int32_t* order, int64_t n_out, const float* scale,
+                    const float* shift, const float* residual, int32_t relu, float* out, int32_t algo,
+                    void* stream);
+/* Pre-pack W (K,Cin,Cout) into the MFMA B-fragment layout used by algo 2 (same byte size). */
+int xm3d_spconv_pack_weight(const float* W, int32_t K, int32_t cin, int32_t cout, float* Wp, void* stream);
+/* dgrad: gin[i,:] = sum over (k,o) with nbr[k,o]==i of gout[o,:] @ W[k]^T, computed as a
+ * forward conv over the INVERSE map nbr_t (K,n_in) (xm3d_kernel_map_invert) with the
+ * per-offset transposed kernels Wt (K,Cout,Cin) (packed for algo 2, like spconv_fwd).
+ * wgrad: gW[k] = sum_o in[nbr[k,o],:]^T gout[o,:]  (gW fully overwritten; f32 atomics). */
+int xm3d_kernel_map_invert(const int32_t* nbr, int32_t K, int64_t n_out, int64_t n_in, int32_t* nbr_t,
+                           void* stream);
+int xm3d_spconv_bwd_data(const float* gout, int64_t n_out, int32_t cout, const float* Wt, int32_t K,
+                         int32_t cin, const int32_t* nbr_t, const int32_t* order, int64_t n_in, float* gin,
+                         int32_t algo, void* stream);
+int xm3d_spconv_bwd_weight(const float* in, int64_t n_in, int32_t cin, const float* gout, int64_t n_out,
+                           int32_t cout, const int32_t* nbr, int32_t K, float* gW, void* stream);
+
+/* Row-wise batch norm over a (n,c) matrix (ME.MinkowskiBatchNorm == BatchNorm1d,
+ * mink_unet.py:51..104).  stats: sum (c) and sumsq (c) in f64 scratch (2*c doubles). */
+int xm3d_bn_stats(const float* x, int64_t n, int32_t c, double* sum_sumsq, void* stream);
+int xm3d_affine_act(const float* x, int64_t n, int32_t c, const float* scale, const float* shift,
+                    const float* residual, int32_t relu, float* out, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * Multi-scale deformable attention (replaces the pybind module
+ * MultiScaleDeformableAttention: third_party/Mask2Former/mask2former/modeling/
+ * pixel_decoder/ops/src/vision.cpp:18-21, ms_deform_attn.h:25-66,
+ * cuda/ms_deform_attn_cuda.cu:25-157).  Same argument meaning and layout:
+ *   value (B,S,H,D) f32, spatial_shapes (L,2) i64 [h,w], level_start (L) i64,
+ *   loc (B,Lq,H,L,P,2) f32 (x,y in [0,1]), attn (B,Lq,H,L,P) f32.
+ * forward : out (B,Lq,H*D) f32, fully overwritten.
+ * backward: grad_value/grad_loc/grad_attn must be ZEROED by the caller
+ *           (the reference allocates them with at::zeros); grad_value is
+ *           accumulated with float atomics like the reference.
+ * ------------------------------------------------------------------------- */
+int xm3d_msda_forward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                      const float* loc, const float* attn, int32_t B, int32_t S, int32_t H, int32_t D,
+                      int32_t L, int32_t Lq, int32_t P, float* out, void* stream);
+int xm3d_msda_backward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                       const float* loc, const float* attn, const float* grad_out, int32_t B, int32_t S,
+                       int32_t H, int32_t D, int32_t L, int32_t Lq, int32_t P, float* grad_value,
+                       float* grad_loc, float* grad_attn, void* stream);
+
+/* ---------------------------------------------------------------------------
+ * 2D->3D mask fusion epilogue (replaces the per-query Python loops of
+ * models/xmask3d.py:421-451 and models/utils/fuser.py:24-35):
+ *   masks (Q,Hm,Wm) u8 (0/1), x/y (n) i64 pixel row/col of each point, embed (Q,C) f32
+ *   feat2d[p,:] = mean over queries q with masks[q,x[p],y[p]] of embed[q,:]  (0 if none)
+ *   count[p]    = number of such queries
+ * ------------------------------------------------------------------------- */
+int xm3d_mask_point_fuse(const uint8_t* masks, int32_t Q, int32_t Hm, int32_t Wm, const int64_t* x,
+                         const int64_t* y, int64_t n, const float* embed, int32_t C, float* feat2d,
+                         int32_t* count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* XM3D_H */

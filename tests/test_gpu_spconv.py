@@ -1,0 +1,151 @@
+"""GPU parity: sparse convolution kernels and the full MinkUNets vs the CPU oracle.
+
+fp32 tolerance: the kernels accumulate in a different (documented) order than the oracle's matmul, so
+results agree to f32 rounding, not bitwise: |err| <= 2e-5 * max|ref| per conv, 1e-3 * max|ref| for the
+whole 63-conv network (BASELINE.json north_star: "per-point logits within 1e-3 fp")."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import spconv_oracle as so
+
+pytestmark = pytest.mark.gpu
+
+
+def _coords(n, seed, hi=40, batches=2):
+    r = np.random.RandomState(seed)
+    c = np.unique(np.concatenate([r.randint(0, batches, (n, 1)), r.randint(0, hi, (n, 3))], 1), axis=0)
+    return c[r.permutation(len(c))].astype(np.int32)
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / max(b.abs().max().item(), 1e-20)
+
+
+@pytest.mark.parametrize("cin,cout,ks,n", [(3, 32, 5, 3000), (32, 32, 3, 5000), (64, 96, 3, 3000), (128, 96, 3, 1000),
+                                           (384, 256, 3, 700), (32, 64, 1, 2000), (96, 32, 3, 1), (32, 32, 3, 255),
+                                           (32, 32, 3, 257)])
+def test_conv_kernels_match_oracle(dev, cin, cout, ks, n):
+    from xmask3d_amd import ops
+
+    torch.manual_seed(n + cin)
+    c = _coords(n, cin + ks)
+    N = len(c)
+    cm = ops.CoordinateManager(torch.from_numpy(c).to(dev))
+    nbr = cm.kernel_map(1, 1, ks)
+    W = torch.randn(ks ** 3, cin, cout) / (cin * 4) ** 0.5
+    f = torch.randn(N, cin)
+    scale, shift, res = torch.rand(cout) + 0.5, torch.randn(cout), torch.randn(N, cout)
+    ref_plain = so.spconv(f.double(), W.double(), nbr.cpu().numpy()).float()
+    ref_epi = torch.relu(ref_plain * scale + shift + res)
+    algos = [ops.ALGO_SCALAR] + ([ops.ALGO_MFMA] if ops.mfma_eligible(cin, cout) else [])
+    for algo in algos:
+        for order in (None, cm.order(1)):
+            out = ops.spconv_fwd(f.to(dev), W.to(dev), nbr, N, order=order, algo=algo)
+            assert _rel(out.cpu(), ref_plain) < 2e-5, (algo, order is None)
+            out = ops.spconv_fwd(f.to(dev), W.to(dev), nbr, N, order=order, scale=scale.to(dev), shift=shift.to(dev),
+                                 residual=res.to(dev), relu=True, algo=algo)
+            assert _rel(out.cpu(), ref_epi) < 2e-5, (algo, order is None)
+
+
+def test_strided_and_transposed_conv(dev):
+    from xmask3d_amd import ops
+
+    torch.manual_seed(3)
+    c = _coords(6000, 9)
+    cm = ops.CoordinateManager(torch.from_numpy(c).to(dev))
+    oc = so.CoordCache(c)
+    f1 = torch.randn(len(c), 32)
+    Wd, Wu = torch.randn(8, 32, 64) * 0.1, torch.randn(8, 64, 32) * 0.1
+    down = ops.spconv_fwd(f1.to(dev), Wd.to(dev), cm.kernel_map(1, 2, 2), cm.num(2))
+    ref_down = so.spconv(f1, Wd, oc.map(1, 2, 2))
+    assert _rel(down.cpu(), ref_down) < 2e-5
+    up = ops.spconv_fwd(down, Wu.to(dev), cm.kernel_map(2, 1, 2, True), cm.num(1), order=cm.order(1))
+    assert _rel(up.cpu(), so.spconv(ref_down, Wu, oc.map(2, 1, 2, True))) < 2e-5
+
+
+def test_empty_input_is_a_noop(dev):
+    from xmask3d_amd import ops
+
+    out = ops.spconv_fwd(torch.zeros(0, 32, device=dev), torch.zeros(27, 32, 32, device=dev),
+                         torch.zeros(27, 0, dtype=torch.int32, device=dev), 0)
+    assert out.shape == (0, 32)
+
+
+def test_bn_stats_and_affine(dev):
+    from xmask3d_amd import ops
+
+    torch.manual_seed(0)
+    x = torch.randn(10007, 96) * 3 + 1
+    s, ss = ops.bn_stats(x.to(dev))
+    assert torch.allclose(s.cpu(), x.double().sum(0), rtol=1e-12) and torch.allclose(ss.cpu(), (x.double() ** 2).sum(0), rtol=1e-12)
+    sc, sh, r = torch.rand(96), torch.randn(96), torch.randn_like(x)
+    y = ops.affine_act(x.to(dev), sc.to(dev), sh.to(dev), r.to(dev), True)
+    assert torch.allclose(y.cpu(), torch.relu(x * sc + sh + r), atol=1e-6)
+
+
+def _randomise_bn(net, seed):
+    g = torch.Generator().manual_seed(seed)
+    for m in net.modules():
+        if isinstance(m, torch.nn.BatchNorm1d):
+            m.running_mean.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+            m.running_var.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.weight.data.copy_(torch.rand(m.num_features, generator=g) + 0.5)
+            m.bias.data.copy_(torch.randn(m.num_features, generator=g) * 0.1)
+
+
+@pytest.mark.parametrize("arch", ["MinkUNet34C", "MinkUNet18A"])
+def test_full_network_matches_oracle(dev, arch):
+    from xmask3d_amd import me_compat as ME
+    from xmask3d_amd.mink_unet import mink_unet
+
+    torch.manual_seed(11)
+    net = mink_unet(3, 256, 3, arch).eval()
+    _randomise_bn(net, 5)
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    c = _coords(9000, 21, hi=48, batches=2)
+    f = torch.rand(len(c), 3) * 2 - 1
+    bott_r, c16, out_r = so.minkunet_forward(params, c, f, arch)
+    net = net.to(dev)
+    with torch.no_grad():
+        bott, out = net(ME.SparseTensor(f.to(dev), torch.from_numpy(c).to(dev)))
+    assert (bott.C.cpu().numpy() == c16).all()
+    assert _rel(out.F.cpu(), out_r) < 1e-3 and _rel(bott.F.cpu(), bott_r) < 1e-3
+
+
+def test_training_mode_batchnorm_matches_oracle(dev):
+    from xmask3d_amd import me_compat as ME
+    from xmask3d_amd.mink_unet import mink_unet
+
+    torch.manual_seed(2)
+    net = mink_unet(3, 32, 3, "MinkUNet14A").train()
+    params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    c = _coords(4000, 5, hi=40, batches=2)
+    f = torch.rand(len(c), 3) * 2 - 1
+    _, _, out_r = so.minkunet_forward(params, c, f, "MinkUNet14A", training=True)
+    net = net.to(dev)
+    with torch.no_grad():
+        _, out = net(ME.SparseTensor(f.to(dev), torch.from_numpy(c).to(dev)))
+    assert _rel(out.F.cpu(), out_r) < 1e-3
+    assert int(net.bn0.bn.num_batches_tracked) == 1
+
+
+def test_reference_style_heads(dev):
+    from xmask3d_amd import me_compat as ME
+    from xmask3d_amd.pc_processor import PC_Binary_Processor, PC_Processor
+
+    torch.manual_seed(4)
+    c = _coords(5000, 8, hi=40, batches=2)
+    f = torch.rand(len(c), 3) * 2 - 1
+    for cls, fn, arch in ((PC_Processor, so.pc_processor_forward, "MinkUNet34C"), (PC_Binary_Processor, so.pc_binary_forward, "MinkUNet18A")):
+        net = cls(arch_3d=arch).eval()
+        params = {k: v.detach().clone() for k, v in net.state_dict().items()}
+        ref = fn(params, c, f, arch)
+        net = net.to(dev)
+        with torch.no_grad():
+            got = net(ME.SparseTensor(f.to(dev), torch.from_numpy(c).to(dev)))
+        if cls is PC_Processor:
+            assert _rel(got[0].cpu(), ref[0]) < 1e-3 and _rel(got[1].cpu(), ref[1]) < 1e-3
+            assert (got[2].cpu().long() == ref[2]).all()
+        else:
+            assert _rel(got.cpu(), ref) < 1e-3

@@ -1,0 +1,82 @@
+"""ctypes binding of libxm3d_hip.so (C ABI declared in include/xm3d.h).
+
+There is NO fallback: if the shared library is missing or a call fails, the
+product path raises.  Build it with ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C xmask3d_amd/csrc``.
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+import re
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libxm3d_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "xm3d.h")
+
+c_i32, c_i64, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p
+
+
+class Xm3dError(RuntimeError):
+    pass
+
+
+_SIGS = {
+    "xm3d_version": (ctypes.c_int, []),
+    "xm3d_last_error": (ctypes.c_char_p, []),
+    "xm3d_device_info": (ctypes.c_int, [ctypes.c_int, ctypes.POINTER(ctypes.c_int), ctypes.POINTER(ctypes.c_int), ctypes.c_char_p]),
+    "xm3d_check_flag": (ctypes.c_int, []),
+    "xm3d_voxelize_ws_bytes": (ctypes.c_int, [c_i64, ctypes.POINTER(c_sz)]),
+    "xm3d_voxelize": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, ctypes.POINTER(c_i64), c_vp, c_sz, c_vp]),
+    "xm3d_fnv_keys": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp]),
+    "xm3d_stride_ws_bytes": (ctypes.c_int, [c_i64, ctypes.POINTER(c_sz)]),
+    "xm3d_coords_stride": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, ctypes.POINTER(c_i64), c_vp, c_sz, c_vp]),
+    "xm3d_coords_order": (ctypes.c_int, [c_vp, c_i64, c_vp, ctypes.POINTER(c_i64), c_vp, c_sz, c_vp]),
+    "xm3d_hash_build": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_vp]),
+    "xm3d_kernel_map": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "xm3d_kernel_map_invert": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i64, c_vp, c_vp]),
+    "xm3d_spconv_fwd": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp]),
+    "xm3d_spconv_pack_weight": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "xm3d_spconv_bwd_data": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp]),
+    "xm3d_spconv_bwd_weight": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp]),
+    "xm3d_bn_stats": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
+    "xm3d_affine_act": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "xm3d_msda_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp]),
+    "xm3d_msda_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp, c_vp, c_vp]),
+    "xm3d_mask_point_fuse": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
+}
+
+_lib = None
+
+
+def header_symbols():
+    """Every entry point include/xm3d.h declares (used by the CPU test that checks the .so exports them)."""
+    with open(HEADER_PATH) as f:
+        txt = f.read()
+    return sorted(set(re.findall(r"\b(xm3d_[a-z0-9_]+)\s*\(", txt)))
+
+
+def lib():
+    """Load (once) and return the shared library with argtypes set.  Raises if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Xm3dError(
+                f"{LIB_PATH} not found: the HIP extension is not built. "
+                "Run `make -C xmask3d_amd/csrc` (or __graft_entry__.build()). There is no CPU fallback."
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in _SIGS.items():
+            fn = getattr(handle, name, None)
+            if fn is None:
+                continue  # declared for a later milestone; calling it raises AttributeError loudly
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        msg = lib().xm3d_last_error()
+        raise Xm3dError(f"{what} failed (code {rc}): {msg.decode() if msg else ''}")

@@ -1,0 +1,63 @@
+// 2D mask -> 3D point feature fusion: for every point, the mean CLIP-space embedding of the mask
+// queries whose (binary) mask covers the point's pixel.  One wave-sized lane group streams the C
+// channels of a point; replaces the <=50-iteration boolean-index scatter loops of
+// models/xmask3d.py:421-451 and models/utils/fuser.py:24-35 with one pass.
+#include "common.h"
+
+namespace xm3d {
+
+// one workgroup row = one point; 64 lanes stride over C/4 channel quads
+__global__ void k_mask_point_fuse(const uint8_t* __restrict__ masks, int Q, int Hm, int Wm, const int64_t* __restrict__ xr,
+                                  const int64_t* __restrict__ yc, int64_t n, const float* __restrict__ embed, int C,
+                                  float* __restrict__ feat2d, int32_t* __restrict__ count) {
+    const int lane = threadIdx.x & 63;
+    const int64_t p = int64_t(blockIdx.x) * (blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (p >= n) return;
+    const int64_t r = xr[p], c = yc[p];
+    const bool ok = r >= 0 && r < Hm && c >= 0 && c < Wm;
+    // lanes test queries lane, lane+64, ... ; ballots give the covering set (ascending q = reference order)
+    int cnt = 0;
+    const int C4 = C / 4;
+    for (int q0 = 0; q0 < Q; q0 += 64) {
+        const int q = q0 + lane;
+        const bool hit = ok && q < Q && masks[(int64_t(q) * Hm + r) * Wm + c] != 0;
+        unsigned long long m = __ballot(hit);
+        cnt += __popcll(m);
+    }
+    for (int c4 = lane; c4 < C4; c4 += 64) {
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q0 = 0; q0 < Q; q0 += 64) {
+            const int q = q0 + lane;
+            const bool hit = ok && q < Q && masks[(int64_t(q) * Hm + r) * Wm + c] != 0;
+            unsigned long long m = __ballot(hit);
+            while (m) {
+                const int b = __ffsll((long long)m) - 1;
+                m &= m - 1;
+                const float4 e = *reinterpret_cast<const float4*>(embed + int64_t(q0 + b) * C + c4 * 4);
+                acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
+            }
+        }
+        const float d = cnt > 0 ? float(cnt) : 1e-5f;  // the reference divides by 1e-5 where no mask covers
+        acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d;
+        *reinterpret_cast<float4*>(feat2d + p * C + c4 * 4) = acc;
+    }
+    if (lane == 0) count[p] = cnt;
+}
+
+}  // namespace xm3d
+
+using namespace xm3d;
+
+extern "C" int xm3d_mask_point_fuse(const uint8_t* masks, int32_t Q, int32_t Hm, int32_t Wm, const int64_t* x,
+                                    const int64_t* y, int64_t n, const float* embed, int32_t C, float* feat2d,
+                                    int32_t* count, void* stream) {
+    XM3D_REQUIRE(Q >= 0 && Hm >= 1 && Wm >= 1 && n >= 0 && C >= 4 && C % 4 == 0, "mask_point_fuse: bad sizes (C %% 4 == 0)");
+    if (n == 0) return XM3D_OK;
+    XM3D_REQUIRE((Q == 0 || (masks && embed)) && x && y && feat2d && count, "mask_point_fuse: null pointer");
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(embed) | reinterpret_cast<uintptr_t>(feat2d)) & 15) == 0,
+                 "mask_point_fuse: embed/feat2d must be 16-byte aligned");
+    hipLaunchKernelGGL(k_mask_point_fuse, dim3((n + 3) / 4), dim3(256), 0, as_stream(stream), masks, Q, Hm, Wm, x, y, n, embed,
+                       C, feat2d, count);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}

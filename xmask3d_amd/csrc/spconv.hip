@@ -1,0 +1,346 @@
+// Sparse convolution over a neighbour table (output-stationary hashed rulebook).
+//
+//   out[o,:] = epi( sum_k in[nbr[k,o],:] @ W[k] ),   W (K,Cin,Cout) f32, nbr (K,n_out) i32 (-1 = hole)
+//
+// algo 1  k_spconv_scalar : one thread per (row, cout); reference-quality kernel, any Cin/Cout.
+// algo 2  k_spconv_mfma   : f32 MFMA (v_mfma_f32_16x16x4_f32, exact f32 fma chains).
+//   * workgroup = 4 waves, 256 output rows (64 per wave, one ballot wide) x 32 output channels
+//   * per kernel offset each wave PACKS its valid (row, neighbour) pairs into dense 16-pair MFMA
+//     tiles, so holes in the rulebook cost padding to 16, not whole zero tiles
+//   * the 32-deep weight chunk W[k][c0:c0+32][ct0:ct0+32] is staged once per workgroup in LDS in
+//     MFMA-fragment order (pre-packed by xm3d_spconv_pack_weight, so the stage is a linear copy)
+//     and shared by the four waves; neighbour rows are gathered straight from global/L2 as
+//     64-byte segments (4 lanes x float4 per row per 16 channels)
+//   * products are computed transposed (D^T = W^T X^T) so a lane ends up with 4 CONSECUTIVE output
+//     channels of one pair and folds them into the wave-private LDS accumulator row of that pair's
+//     output row with one 16-byte read-modify-write (no atomics; deterministic summation order:
+//     offsets ascending, 32-channel chunks ascending, fma chain inside)
+//   * epilogue: scale/shift (folded BatchNorm), residual add, ReLU, coalesced row stores
+//
+// Replaces ME.MinkowskiConvolution(+Transpose) and the BN/ReLU/residual tail of ME's BasicBlock
+// (call sites: models/modeling/meta_arch/mink_unet.py:47-109,118-178, resnet_base.py:64-96).
+#include "common.h"
+
+namespace xm3d {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ------------------------------------------------------------------ scalar kernel
+__global__ void k_spconv_scalar(const float* __restrict__ in, int cin, const float* __restrict__ W, int K, int cout,
+                                const int32_t* __restrict__ nbr, int64_t n_out, const float* __restrict__ scale,
+                                const float* __restrict__ shift, const float* __restrict__ residual, int relu,
+                                float* __restrict__ out) {
+    const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e >= n_out * cout) return;
+    const int64_t o = e / cout;
+    const int c = int(e % cout);
+    float acc = 0.f;
+    for (int k = 0; k < K; ++k) {
+        const int i = nbr ? nbr[int64_t(k) * n_out + o] : int(o);
+        if (i < 0) continue;
+        const float* x = in + int64_t(i) * cin;
+        const float* w = W + (int64_t(k) * cin) * cout + c;
+        float part = 0.f;
+        for (int ci = 0; ci < cin; ++ci) part = fmaf(x[ci], w[int64_t(ci) * cout], part);
+        acc += part;
+    }
+    if (scale) acc *= scale[c];
+    if (shift) acc += shift[c];
+    if (residual) acc += residual[e];
+    if (relu) acc = fmaxf(acc, 0.f);
+    out[e] = acc;
+}
+
+// ------------------------------------------------------------------ weight packing
+// Wp[((k*CS + cs)*NS + ns)*256 + lane*4 + jj] = W[k][16cs + 4(lane>>4) + jj][16ns + (lane&15)]
+__global__ void k_pack_weight(const float* __restrict__ W, int K, int cin, int cout, float* __restrict__ Wp) {
+    const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    const int64_t total = int64_t(K) * cin * cout;
+    if (e >= total) return;
+    const int jj = int(e & 3);
+    const int lane = int((e >> 2) & 63);
+    const int64_t blk = e >> 8;
+    const int NS = cout / 16, CS = cin / 16;
+    const int ns = int(blk % NS);
+    const int cs = int((blk / NS) % CS);
+    const int k = int(blk / (int64_t(NS) * CS));
+    const int ci = 16 * cs + 4 * (lane >> 4) + jj;
+    const int co = 16 * ns + (lane & 15);
+    Wp[e] = W[(int64_t(k) * cin + ci) * cout + co];
+}
+
+// ------------------------------------------------------------------ MFMA kernel
+constexpr int RW = 64;        // rows per wave
+constexpr int WAVES = 4;      // waves per workgroup
+constexpr int CT = 32;        // output channels per workgroup
+constexpr int NT = CT / 16;   // 16-wide channel tiles
+constexpr int CK = 32;        // input-channel chunk staged per step
+constexpr int ST = CK / 16;   // 16-deep k-steps per chunk
+constexpr int ACC_LD = CT + 4;  // padded accumulator row (floats): 16-byte aligned, breaks bank stride
+
+struct __attribute__((aligned(16))) SpconvLds {
+    float acc[WAVES][RW][ACC_LD];     // wave-private accumulators
+    float w[ST * NT * 256];           // staged weight chunk, fragment order
+    int src[WAVES][RW];               // packed pair -> input row
+    int dst[WAVES][RW];               // packed pair -> local output row
+};
+
+__global__ __launch_bounds__(256, 2) void k_spconv_mfma(const float* __restrict__ in, int cin, const float* __restrict__ Wp,
+                                                         int K, int cout, const int32_t* __restrict__ nbr,
+                                                         const int32_t* __restrict__ order, int64_t n_out,
+                                                         const float* __restrict__ scale, const float* __restrict__ shift,
+                                                         const float* __restrict__ residual, int relu,
+                                                         float* __restrict__ out) {
+    __shared__ SpconvLds lds;
+    const int tid = threadIdx.x;
+    const int wave = tid >> 6;
+    const int lane = tid & 63;
+    const int p16 = lane & 15;  // pair slot inside an MFMA tile / cout inside a tile (A side)
+    const int kq = lane >> 4;   // k quarter (operands) / cout quarter (result)
+    const int ct0 = blockIdx.y * CT;
+    const int NS = cout / 16, CS = cin / 16;
+
+    // this lane's output row
+    const int64_t slot = int64_t(blockIdx.x) * (RW * WAVES) + wave * RW + lane;
+    int64_t row = -1;
+    if (slot < n_out) row = order ? order[slot] : slot;
+
+    for (int c = lane; c < RW * ACC_LD; c += 64) (&lds.acc[wave][0][0])[c] = 0.f;
+
+    for (int k = 0; k < K; ++k) {
+        int v = -1;
+        if (row >= 0) v = nbr ? nbr[int64_t(k) * n_out + row] : int(row);
+        const unsigned long long m = __ballot(v >= 0);
+        const int cnt = __popcll(m);
+        if (__syncthreads_or(cnt) == 0) continue;  // nobody in the workgroup uses this offset
+        if (v >= 0) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            lds.src[wave][rank] = v;
+            lds.dst[wave][rank] = lane;
+        }
+        const int ntile = (cnt + 15) >> 4;
+        for (int cc = 0; cc < cin / CK; ++cc) {
+            // stage W[k][cc*CK .. +CK][ct0 .. +CT] (already in fragment order): ST*NT blocks of 1 KiB
+            __syncthreads();  // previous chunk fully consumed (and src/dst visible)
+            {
+                const int b = tid >> 6;  // one 1-KiB block per wave when ST*NT == 4
+                for (int blk = b; blk < ST * NT; blk += WAVES) {
+                    const int s = blk / NT, n = blk % NT;
+                    const int64_t g = ((int64_t(k) * CS + (cc * ST + s)) * NS + (ct0 / 16 + n)) * 256 + lane * 4;
+                    *reinterpret_cast<f32x4*>(&lds.w[blk * 256 + lane * 4]) = *reinterpret_cast<const f32x4*>(Wp + g);
+                }
+            }
+            __syncthreads();
+            for (int t = 0; t < ntile; ++t) {
+                const int p = t * 16 + p16;
+                const int srow = (p < cnt) ? lds.src[wave][p] : -1;
+                f32x4 x[ST];
+#pragma unroll
+                for (int s = 0; s < ST; ++s) {
+                    x[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+                    if (srow >= 0)
+                        x[s] = *reinterpret_cast<const f32x4*>(in + int64_t(srow) * cin + cc * CK + s * 16 + kq * 4);
+                }
+                const int drow = (p < cnt) ? lds.dst[wave][p] : -1;
+#pragma unroll
+                for (int n = 0; n < NT; ++n) {
+                    f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                    for (int s = 0; s < ST; ++s) {
+                        const f32x4 w = *reinterpret_cast<const f32x4*>(&lds.w[(s * NT + n) * 256 + lane * 4]);
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x[s][0], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x[s][1], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x[s][2], d, 0, 0, 0);
+                        d = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], x[s][3], d, 0, 0, 0);
+                    }
+                    // d[j] = result for pair p16, channel ct0 + 16n + 4kq + j
+                    if (drow >= 0) {
+                        f32x4* a = reinterpret_cast<f32x4*>(&lds.acc[wave][drow][n * 16 + kq * 4]);
+                        f32x4 cur = *a;
+                        cur += d;
+                        *a = cur;
+                    }
+                }
+            }
+        }
+    }
+    // epilogue: each wave writes its own 64 rows; 8 lanes x float4 cover one 32-channel row
+    __builtin_amdgcn_s_waitcnt(0xC07F);  // lgkmcnt(0): own LDS RMWs done (wave-private rows)
+    const int rsub = lane >> 3;          // 0..7 row inside an 8-row group
+    const int c4 = (lane & 7) * 4;       // channel offset
+    for (int r0 = 0; r0 < RW; r0 += 8) {
+        const int lr = r0 + rsub;
+        const int64_t sl = int64_t(blockIdx.x) * (RW * WAVES) + wave * RW + lr;
+        if (sl >= n_out) continue;
+        const int64_t grow = order ? order[sl] : sl;
+        f32x4 vacc = *reinterpret_cast<const f32x4*>(&lds.acc[wave][lr][c4]);
+        const int c = ct0 + c4;
+        if (scale) vacc *= *reinterpret_cast<const f32x4*>(scale + c);
+        if (shift) vacc += *reinterpret_cast<const f32x4*>(shift + c);
+        if (residual) vacc += *reinterpret_cast<const f32x4*>(residual + grow * cout + c);
+        if (relu) {
+            vacc[0] = fmaxf(vacc[0], 0.f);
+            vacc[1] = fmaxf(vacc[1], 0.f);
+            vacc[2] = fmaxf(vacc[2], 0.f);
+            vacc[3] = fmaxf(vacc[3], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(out + grow * cout + c) = vacc;
+    }
+}
+
+// ------------------------------------------------------------------ weight gradient
+// gW[k][ci][co] = sum_o in[nbr[k,o]][ci] * gout[o][co].
+// grid = (row chunks, (cin/32)*(cout/32) tiles, K); each wave owns one 32x32 tile of gW[k] and a slice of
+// the chunk's rows: valid (in,out) pairs are compacted with a ballot, consumed 4 at a time by
+// v_mfma_f32_16x16x4_f32 (A = X^T: lane (ci, pair), B = G: lane (pair, co), both 64-byte row segments
+// straight from global/L2), and the tile is folded into gW with f32 atomics (order-dependent last bits,
+// like every atomics-based wgrad; K*cin*cout*4 bytes per chunk, far below the 1.3 TB/s atomic ceiling).
+constexpr int WG_ROWS = 2048;  // rows per workgroup chunk (512 per wave)
+
+__global__ __launch_bounds__(256) void k_spconv_wgrad_mfma(const float* __restrict__ in, int cin,
+                                                            const float* __restrict__ gout, int cout,
+                                                            const int32_t* __restrict__ nbr, int64_t n_out,
+                                                            float* __restrict__ gW) {
+    __shared__ int s_src[WAVES][64];
+    __shared__ int s_dst[WAVES][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int k = blockIdx.z;
+    const int tiles_co = cout / 32;
+    const int ci0 = (blockIdx.y / tiles_co) * 32, co0 = (blockIdx.y % tiles_co) * 32;
+    const int l16 = lane & 15, pq = lane >> 4;
+    f32x4 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) acc[a][b] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const int64_t base = int64_t(blockIdx.x) * WG_ROWS + wave * (WG_ROWS / WAVES);
+    for (int64_t r0 = base; r0 < base + WG_ROWS / WAVES && r0 < n_out; r0 += 64) {
+        const int64_t o = r0 + lane;
+        int v = -1;
+        if (o < n_out) v = nbr ? nbr[int64_t(k) * n_out + o] : int(o);
+        const unsigned long long m = __ballot(v >= 0);
+        const int cnt = __popcll(m);
+        if (cnt == 0) continue;
+        if (v >= 0) {
+            const int rank = __popcll(m & ((1ull << lane) - 1ull));
+            s_src[wave][rank] = v;
+            s_dst[wave][rank] = int(o - r0);
+        }
+        for (int p0 = 0; p0 < cnt; p0 += 4) {
+            const int p = p0 + pq;
+            const bool ok = p < cnt;
+            const int64_t si = ok ? s_src[wave][p] : 0;
+            const int64_t di = ok ? r0 + s_dst[wave][p] : 0;
+            float x[2], g[2];
+#pragma unroll
+            for (int t = 0; t < 2; ++t) {
+                x[t] = ok ? in[si * cin + ci0 + 16 * t + l16] : 0.f;
+                g[t] = ok ? gout[di * cout + co0 + 16 * t + l16] : 0.f;
+            }
+#pragma unroll
+            for (int a = 0; a < 2; ++a)
+#pragma unroll
+                for (int b = 0; b < 2; ++b) acc[a][b] = __builtin_amdgcn_mfma_f32_16x16x4f32(x[a], g[b], acc[a][b], 0, 0, 0);
+        }
+    }
+    // D[i = ci][j = co]: lane holds co = l16, ci = 4*pq + reg
+    float* dst = gW + (int64_t(k) * cin) * cout;
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float val = acc[a][b][j];
+                if (val != 0.f) atomicAdd(dst + int64_t(ci0 + 16 * a + 4 * pq + j) * cout + co0 + 16 * b + l16, val);
+            }
+}
+
+// any channel count: one workgroup per (row chunk, k); threads stride over the cin*cout elements
+__global__ void k_spconv_wgrad_scalar(const float* __restrict__ in, int cin, const float* __restrict__ gout, int cout,
+                                      const int32_t* __restrict__ nbr, int64_t n_out, float* __restrict__ gW) {
+    const int k = blockIdx.y;
+    const int64_t r0 = int64_t(blockIdx.x) * WG_ROWS;
+    const int64_t r1 = (r0 + WG_ROWS < n_out) ? r0 + WG_ROWS : n_out;
+    for (int e = threadIdx.x; e < cin * cout; e += blockDim.x) {
+        const int ci = e / cout, co = e % cout;
+        float acc = 0.f;
+        for (int64_t o = r0; o < r1; ++o) {
+            const int i = nbr ? nbr[int64_t(k) * n_out + o] : int(o);
+            if (i >= 0) acc = fmaf(in[int64_t(i) * cin + ci], gout[o * cout + co], acc);
+        }
+        if (acc != 0.f) atomicAdd(gW + (int64_t(k) * cin + ci) * cout + co, acc);
+    }
+}
+
+}  // namespace xm3d
+
+using namespace xm3d;
+
+extern "C" int xm3d_spconv_pack_weight(const float* W, int32_t K, int32_t cin, int32_t cout, float* Wp, void* stream) {
+    XM3D_REQUIRE(W && Wp && K >= 1, "pack_weight: bad args");
+    XM3D_REQUIRE(cin % 16 == 0 && cout % 16 == 0, "pack_weight: cin=%d cout=%d must be multiples of 16", cin, cout);
+    const int64_t total = int64_t(K) * cin * cout;
+    hipLaunchKernelGGL(k_pack_weight, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), W, K, cin, cout, Wp);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+extern "C" int xm3d_spconv_fwd(const float* in, int64_t n_in, int32_t cin, const float* W, int32_t K, int32_t cout,
+                               const int32_t* nbr, const int32_t* order, int64_t n_out, const float* scale,
+                               const float* shift, const float* residual, int32_t relu, float* out, int32_t algo,
+                               void* stream) {
+    XM3D_REQUIRE(n_in >= 0 && n_out >= 0 && cin >= 1 && cout >= 1 && K >= 1, "spconv_fwd: bad sizes");
+    XM3D_REQUIRE(n_out * int64_t(cout) < (int64_t(1) << 40), "spconv_fwd: output too large");
+    if (n_out == 0) return XM3D_OK;
+    XM3D_REQUIRE(in && W && out, "spconv_fwd: null pointer");
+    XM3D_REQUIRE(nbr || (K == 1 && n_in == n_out), "spconv_fwd: nbr may be NULL only for K=1 identity maps");
+    const bool mfma_ok = (cin % CK == 0) && (cout % CT == 0);
+    if (algo == 0) algo = mfma_ok ? 2 : 1;
+    hipStream_t s = as_stream(stream);
+    if (algo == 1) {
+        const int64_t total = n_out * cout;
+        hipLaunchKernelGGL(k_spconv_scalar, dim3((total + 255) / 256), dim3(256), 0, s, in, cin, W, K, cout, nbr, n_out,
+                           scale, shift, residual, relu, out);
+    } else if (algo == 2) {
+        XM3D_REQUIRE(mfma_ok, "spconv_fwd: algo 2 needs cin %% %d == 0 and cout %% %d == 0 (got %d, %d)", CK, CT, cin, cout);
+        XM3D_REQUIRE((reinterpret_cast<uintptr_t>(in) & 15) == 0 && (reinterpret_cast<uintptr_t>(out) & 15) == 0 &&
+                         (reinterpret_cast<uintptr_t>(W) & 15) == 0,
+                     "spconv_fwd: algo 2 needs 16-byte aligned tensors");
+        // for algo 2, W must be the packed layout produced by xm3d_spconv_pack_weight
+        dim3 grid((n_out + RW * WAVES - 1) / (RW * WAVES), cout / CT);
+        hipLaunchKernelGGL(k_spconv_mfma, grid, dim3(256), 0, s, in, cin, W, K, cout, nbr, order, n_out, scale, shift,
+                           residual, relu, out);
+    } else {
+        XM3D_REQUIRE(false, "spconv_fwd: unknown algo %d", algo);
+    }
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+extern "C" int xm3d_spconv_bwd_data(const float* gout, int64_t n_out, int32_t cout, const float* Wt, int32_t K,
+                                    int32_t cin, const int32_t* nbr_t, const int32_t* order, int64_t n_in, float* gin,
+                                    int32_t algo, void* stream) {
+    // gin = conv(gout) over the inverse map with per-offset transposed kernels Wt[k] = W[k]^T  (K, Cout, Cin)
+    return xm3d_spconv_fwd(gout, n_out, cout, Wt, K, cin, nbr_t, order, n_in, nullptr, nullptr, nullptr, 0, gin, algo,
+                           stream);
+}
+
+extern "C" int xm3d_spconv_bwd_weight(const float* in, int64_t n_in, int32_t cin, const float* gout, int64_t n_out,
+                                      int32_t cout, const int32_t* nbr, int32_t K, float* gW, void* stream) {
+    XM3D_REQUIRE(n_in >= 0 && n_out >= 0 && cin >= 1 && cout >= 1 && K >= 1 && gW, "spconv_bwd_weight: bad args");
+    XM3D_REQUIRE(nbr || (K == 1 && n_in == n_out), "spconv_bwd_weight: nbr may be NULL only for K=1 identity maps");
+    hipStream_t s = as_stream(stream);
+    XM3D_HIP(hipMemsetAsync(gW, 0, size_t(K) * cin * cout * sizeof(float), s));
+    if (n_out == 0 || n_in == 0) return XM3D_OK;
+    XM3D_REQUIRE(in && gout, "spconv_bwd_weight: null pointer");
+    const int chunks = int((n_out + WG_ROWS - 1) / WG_ROWS);
+    if (cin % 32 == 0 && cout % 32 == 0) {
+        hipLaunchKernelGGL(k_spconv_wgrad_mfma, dim3(chunks, (cin / 32) * (cout / 32), K), dim3(256), 0, s, in, cin, gout, cout,
+                           nbr, n_out, gW);
+    } else {
+        hipLaunchKernelGGL(k_spconv_wgrad_scalar, dim3(chunks, K), dim3(256), 0, s, in, cin, gout, cout, nbr, n_out, gW);
+    }
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}

@@ -1,0 +1,438 @@
+"""MinkowskiEngine-compatible operator surface backed by libxm3d_hip.so.
+
+This is the drop-in seam of SURVEY.md §8b "Sparse operator seam": the names,
+constructor arguments, parameter names/shapes (``kernel`` (K,Cin,Cout) or
+(Cin,Cout) for k=1, ``bn.*``) and call conventions the reference uses from
+``import MinkowskiEngine as ME``
+(/root/reference/models/modeling/meta_arch/mink_unet.py:25-26,47-116,
+resnet_base.py:3-4,55-96, pc_processor.py:31-33,57, run/train.py:18,35,186,483).
+``install_as_minkowski_engine()`` registers this module under that name so the
+reference's model files import unchanged.
+
+Design (MI355X-first, not ME's): coordinates are hashed once per forward by a
+shared CoordinateManager; every conv is ONE output-stationary HIP kernel over a
+neighbour table; and the module-by-module call pattern the reference writes
+(conv -> bn -> relu, ``out += residual``) is folded into that kernel's epilogue
+by lazy evaluation: a conv returns a SparseTensor whose features are *pending*;
+eval-mode BatchNorm, ReLU and the residual add attach to the pending epilogue,
+and the kernel launches when somebody needs the features (``.F``, the next
+conv, ``cat``).  Training-mode BatchNorm materialises the conv, reduces
+statistics with a HIP kernel and leaves a pending fused affine(+residual)(+ReLU).
+"""
+from __future__ import annotations
+
+import math
+import sys
+import types
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+# ----------------------------------------------------------------------------- tensors
+class _PendingConv:
+    def __init__(self, feats, kernel3, packed, nbr, order, n_out):
+        self.feats, self.kernel3, self.packed = feats, kernel3, packed
+        self.nbr, self.order, self.n_out = nbr, order, n_out
+        self.scale = self.shift = self.residual = None
+        self.relu = False
+
+    def can_fold_affine(self):
+        return self.residual is None and not self.relu
+
+    def run(self):
+        return ops.spconv_fwd(self.feats, self.kernel3, self.nbr, self.n_out, order=self.order, scale=self.scale,
+                              shift=self.shift, residual=self.residual, relu=self.relu, packed=self.packed)
+
+
+class _PendingAffine:
+    def __init__(self, x, scale, shift):
+        self.x, self.scale, self.shift = x, scale, shift
+        self.residual = None
+        self.relu = False
+
+    def can_fold_affine(self):
+        return False
+
+    def run(self):
+        return ops.affine_act(self.x, self.scale, self.shift, self.residual, self.relu)
+
+
+class SparseTensor:
+    """Features (N,C) f32 + int32 coordinates (N,4) [batch,x,y,z] at a tensor stride."""
+
+    def __init__(self, features=None, coordinates=None, tensor_stride=1, coordinate_manager=None, _pending=None):
+        if coordinate_manager is None:
+            if coordinates is None:
+                raise ValueError("SparseTensor needs coordinates or a coordinate_manager")
+            if coordinates.dtype != torch.int32:
+                coordinates = coordinates.int()
+            coordinate_manager = ops.CoordinateManager(coordinates.contiguous())
+            coordinate_manager.order(1)  # also verifies uniqueness, like ME's default quantisation mode
+        self.coordinate_manager = coordinate_manager
+        self.tensor_stride = tensor_stride
+        self._F = None
+        self._pending = _pending
+        if features is not None:
+            if features.dtype != torch.float32:
+                features = features.float()
+            self._F = features.contiguous()
+            if self._F.shape[0] != coordinate_manager.num(tensor_stride):
+                raise RuntimeError("features and coordinates have different numbers of rows")
+
+    # ME attribute names
+    @property
+    def F(self):
+        if self._F is None:
+            self._F = self._pending.run()
+            self._pending = None
+        return self._F
+
+    @property
+    def C(self):
+        return self.coordinate_manager.coords(self.tensor_stride)
+
+    @property
+    def features(self):
+        return self.F
+
+    @property
+    def coordinates(self):
+        return self.C
+
+    @property
+    def shape(self):
+        if self._F is not None:
+            return self._F.shape
+        p = self._pending
+        return torch.Size((p.n_out, p.kernel3.shape[2])) if isinstance(p, _PendingConv) else p.x.shape
+
+    def _like(self, features=None, pending=None):
+        return SparseTensor(features, tensor_stride=self.tensor_stride, coordinate_manager=self.coordinate_manager,
+                            _pending=pending)
+
+    def __add__(self, other):
+        return _add(self, other)
+
+    def __iadd__(self, other):
+        return _add(self, other)
+
+
+def _add(a: SparseTensor, b: SparseTensor) -> SparseTensor:
+    if a.coordinate_manager is not b.coordinate_manager or a.tensor_stride != b.tensor_stride:
+        raise RuntimeError("adding SparseTensors that live on different coordinate maps")
+    if a._pending is not None and a._pending.residual is None and not a._pending.relu:
+        a._pending.residual = b.F
+        return a
+    if b._pending is not None and b._pending.residual is None and not b._pending.relu:
+        b._pending.residual = a.F
+        return b
+    p = _PendingAffine(a.F, None, None)
+    p.residual = b.F
+    return a._like(pending=p)
+
+
+def cat(*tensors):
+    if len(tensors) == 1 and isinstance(tensors[0], (list, tuple)):
+        tensors = tuple(tensors[0])
+    t0 = tensors[0]
+    for t in tensors[1:]:
+        if t.coordinate_manager is not t0.coordinate_manager or t.tensor_stride != t0.tensor_stride:
+            raise RuntimeError("ME.cat needs tensors on the same coordinate map")
+    return t0._like(torch.cat([t.F for t in tensors], dim=1))
+
+
+# ----------------------------------------------------------------------------- modules
+class _ConvBase(nn.Module):
+    transposed = False
+
+    def __init__(self, in_channels, out_channels, kernel_size=-1, stride=1, dilation=1, bias=False,
+                 kernel_generator=None, expand_coordinates=False, convolution_mode=None, dimension=None):
+        super().__init__()
+        if dimension not in (None, 3):
+            raise NotImplementedError("only dimension=3 is on the XMask3D path")
+        if dilation != 1 or kernel_generator is not None or expand_coordinates:
+            raise NotImplementedError("dilation / custom kernel generators / expand_coordinates are not on the XMask3D path")
+        self.in_channels, self.out_channels = in_channels, out_channels
+        self.kernel_size, self.stride, self.dimension = int(kernel_size), int(stride), 3
+        kv = self.kernel_size ** 3
+        self.kernel_volume = kv
+        shape = (in_channels, out_channels) if kv == 1 else (kv, in_channels, out_channels)
+        self.kernel = nn.Parameter(torch.empty(*shape))
+        self.bias = nn.Parameter(torch.empty(1, out_channels)) if bias else None
+        self.reset_parameters()
+        self._packed = None
+        self._packed_key = None
+
+    def reset_parameters(self):
+        with torch.no_grad():
+            n = (self.out_channels if self.transposed else self.in_channels) * self.kernel_volume
+            stdv = 1.0 / math.sqrt(n)
+            self.kernel.uniform_(-stdv, stdv)
+            if self.bias is not None:
+                self.bias.uniform_(-stdv, stdv)
+
+    def _kernel3(self):
+        return self.kernel if self.kernel.dim() == 3 else self.kernel.unsqueeze(0)
+
+    def _packed_weight(self, k3):
+        if not ops.mfma_eligible(self.in_channels, self.out_channels):
+            return None
+        key = (k3.data_ptr(), self.kernel._version, k3.device)
+        if self._packed_key != key:
+            self._packed = ops.pack_weight(k3.detach().contiguous())
+            self._packed_key = key
+        return self._packed
+
+    def _strides(self, ts_in):
+        if self.transposed:
+            if ts_in % self.stride:
+                raise RuntimeError("transposed conv on a tensor stride that is not a multiple of its stride")
+            return ts_in // self.stride
+        return ts_in * self.stride
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        cm = x.coordinate_manager
+        ts_in = x.tensor_stride
+        ts_out = self._strides(ts_in)
+        feats = x.F
+        if torch.is_grad_enabled() and (feats.requires_grad or self.kernel.requires_grad):
+            raise NotImplementedError(
+                "sparse-conv backward (xm3d_spconv_bwd_data / _bwd_weight) is not part of this build yet; "
+                "run the 3D backbone under torch.no_grad()")
+        k3 = self._kernel3().detach()
+        if not k3.is_contiguous():
+            k3 = k3.contiguous()
+        n_out = cm.num(ts_out)
+        if self.kernel_volume == 1 and self.stride == 1:
+            nbr = None
+        else:
+            nbr = cm.kernel_map(ts_in, ts_out, self.kernel_size, self.transposed)
+        pend = _PendingConv(feats, k3, self._packed_weight(k3), nbr, cm.order(ts_out), n_out)
+        if self.bias is not None:
+            pend.shift = self.bias.detach().reshape(-1).contiguous()
+        return SparseTensor(tensor_stride=ts_out, coordinate_manager=cm, _pending=pend)
+
+
+class MinkowskiConvolution(_ConvBase):
+    transposed = False
+
+
+class MinkowskiConvolutionTranspose(_ConvBase):
+    transposed = True
+
+
+class MinkowskiBatchNorm(nn.Module):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, affine=True, track_running_stats=True):
+        super().__init__()
+        self.bn = nn.BatchNorm1d(num_features, eps=eps, momentum=momentum, affine=affine,
+                                 track_running_stats=track_running_stats)
+
+    def _scale_shift(self, mean, var):
+        bn = self.bn
+        inv = torch.rsqrt(var + bn.eps)
+        scale = inv * bn.weight.detach() if bn.affine else inv
+        shift = -mean * scale
+        if bn.affine:
+            shift = shift + bn.bias.detach()
+        return scale.float().contiguous(), shift.float().contiguous()
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        bn = self.bn
+        use_batch = self.training or not bn.track_running_stats
+        if not use_batch:
+            scale, shift = self._scale_shift(bn.running_mean, bn.running_var)
+            p = x._pending
+            if p is not None and p.can_fold_affine():
+                if p.scale is None and p.shift is None:
+                    p.scale, p.shift = scale, shift
+                else:  # conv bias already sits in shift
+                    s0 = p.scale if p.scale is not None else torch.ones_like(scale)
+                    b0 = p.shift if p.shift is not None else torch.zeros_like(shift)
+                    p.scale, p.shift = s0 * scale, b0 * scale + shift
+                return x
+            return x._like(pending=_PendingAffine(x.F, scale, shift))
+        feats = x.F
+        n = feats.shape[0]
+        s, ss = ops.bn_stats(feats)
+        mean = s / max(n, 1)
+        var = (ss / max(n, 1) - mean * mean).clamp_min(0.0)
+        if self.training and bn.track_running_stats:
+            with torch.no_grad():
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                unbiased = var * (n / max(n - 1, 1))
+                bn.running_mean.mul_(1 - m).add_(mean.float(), alpha=m)
+                bn.running_var.mul_(1 - m).add_(unbiased.float(), alpha=m)
+                bn.num_batches_tracked += 1
+        scale, shift = self._scale_shift(mean, var)
+        return x._like(pending=_PendingAffine(feats, scale, shift))
+
+
+class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
+    """Statistics all-reduced over the default process group (RCCL on ROCm)."""
+
+    @classmethod
+    def convert_sync_batchnorm(cls, module, process_group=None):
+        """Recursively swap MinkowskiBatchNorm for the synchronised variant (parameters are shared, not copied)."""
+        if isinstance(module, MinkowskiBatchNorm) and not isinstance(module, cls):
+            bn = module.bn
+            new = cls(bn.num_features, bn.eps, bn.momentum, bn.affine, bn.track_running_stats)
+            new.bn = bn
+            new.train(module.training)
+            return new
+        for name, child in list(module.named_children()):
+            setattr(module, name, cls.convert_sync_batchnorm(child, process_group))
+        return module
+
+    def forward(self, x):
+        import torch.distributed as dist
+
+        if not (self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
+            return super().forward(x)
+        bn = self.bn
+        feats = x.F
+        s, ss = ops.bn_stats(feats)
+        packed = torch.cat([s, ss, torch.tensor([float(feats.shape[0])], dtype=torch.float64, device=feats.device)])
+        dist.all_reduce(packed)  # one fused (2C+1)-double all-reduce per layer
+        c = feats.shape[1]
+        n = packed[-1]
+        mean = packed[:c] / n
+        var = (packed[c:2 * c] / n - mean * mean).clamp_min(0.0)
+        if bn.track_running_stats:
+            with torch.no_grad():
+                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                unbiased = var * (n / (n - 1).clamp_min(1))
+                bn.running_mean.mul_(1 - m).add_(mean.float(), alpha=m)
+                bn.running_var.mul_(1 - m).add_(unbiased.float(), alpha=m)
+                bn.num_batches_tracked += 1
+        scale, shift = self._scale_shift(mean, var)
+        return x._like(pending=_PendingAffine(feats, scale, shift))
+
+
+class MinkowskiReLU(nn.Module):
+    def __init__(self, inplace=False):
+        super().__init__()
+        self.inplace = inplace
+
+    def forward(self, x: SparseTensor) -> SparseTensor:
+        if x._pending is not None:
+            x._pending.relu = True  # relu is idempotent, folding twice is harmless
+            return x
+        p = _PendingAffine(x.F, None, None)
+        p.relu = True
+        return x._like(pending=p)
+
+
+class MinkowskiLinear(nn.Module):
+    def __init__(self, in_features, out_features, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+
+    def forward(self, x):
+        return x._like(self.linear(x.F))
+
+
+class _NotOnPath(nn.Module):
+    """Imported by resnet_base.py but never executed by MinkUNet (constructed only by ResNetBase)."""
+
+    def __init__(self, *a, **k):
+        super().__init__()
+
+    def forward(self, x):
+        raise NotImplementedError(f"{type(self).__name__} is not on the XMask3D hot path")
+
+
+class MinkowskiAvgPooling(_NotOnPath):
+    pass
+
+
+class MinkowskiGlobalMaxPooling(_NotOnPath):
+    pass
+
+
+# ----------------------------------------------------------------------------- resnet blocks
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, bn_momentum=0.1, dimension=-1):
+        super().__init__()
+        assert dimension > 0
+        self.conv1 = MinkowskiConvolution(inplanes, planes, kernel_size=3, stride=stride, dilation=dilation,
+                                          dimension=dimension)
+        self.norm1 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv2 = MinkowskiConvolution(planes, planes, kernel_size=3, stride=1, dilation=dilation,
+                                          dimension=dimension)
+        self.norm2 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.relu = MinkowskiReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        residual = x
+        out = self.relu(self.norm1(self.conv1(x)))
+        out = self.norm2(self.conv2(out))
+        if self.downsample is not None:
+            residual = self.downsample(x)
+        out += residual
+        return self.relu(out)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, bn_momentum=0.1, dimension=-1):
+        super().__init__()
+        assert dimension > 0
+        self.conv1 = MinkowskiConvolution(inplanes, planes, kernel_size=1, dimension=dimension)
+        self.norm1 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv2 = MinkowskiConvolution(planes, planes, kernel_size=3, stride=stride, dilation=dilation,
+                                          dimension=dimension)
+        self.norm2 = MinkowskiBatchNorm(planes, momentum=bn_momentum)
+        self.conv3 = MinkowskiConvolution(planes, planes * self.expansion, kernel_size=1, dimension=dimension)
+        self.norm3 = MinkowskiBatchNorm(planes * self.expansion, momentum=bn_momentum)
+        self.relu = MinkowskiReLU(inplace=True)
+        self.downsample = downsample
+
+    def forward(self, x):
+        residual = x
+        out = self.relu(self.norm1(self.conv1(x)))
+        out = self.relu(self.norm2(self.conv2(out)))
+        out = self.norm3(self.conv3(out))
+        if self.downsample is not None:
+            residual = self.downsample(x)
+        out += residual
+        return self.relu(out)
+
+
+# ----------------------------------------------------------------------------- utils
+def kaiming_normal_(tensor, a=0, mode="fan_in", nonlinearity="leaky_relu"):
+    """ME.utils.kaiming_normal_: fans computed for (K, Cin, Cout) / (Cin, Cout) kernels."""
+    if tensor.dim() == 2:
+        fan_in, fan_out = tensor.size(0), tensor.size(1)
+    else:
+        kv = tensor.size(0)
+        fan_in, fan_out = tensor.size(1) * kv, tensor.size(2) * kv
+    fan = fan_in if mode == "fan_in" else fan_out
+    std = nn.init.calculate_gain(nonlinearity, a) / math.sqrt(fan)
+    with torch.no_grad():
+        return tensor.normal_(0, std)
+
+
+utils = types.ModuleType("MinkowskiEngine.utils")
+utils.kaiming_normal_ = kaiming_normal_
+
+
+def install_as_minkowski_engine():
+    """Make ``import MinkowskiEngine as ME`` resolve to this module (drop-in for the reference's model files)."""
+    me = sys.modules[__name__]
+    modules = types.ModuleType("MinkowskiEngine.modules")
+    resnet_block = types.ModuleType("MinkowskiEngine.modules.resnet_block")
+    resnet_block.BasicBlock, resnet_block.Bottleneck = BasicBlock, Bottleneck
+    modules.resnet_block = resnet_block
+    me.modules = modules
+    sys.modules["MinkowskiEngine"] = me
+    sys.modules["MinkowskiEngine.modules"] = modules
+    sys.modules["MinkowskiEngine.modules.resnet_block"] = resnet_block
+    sys.modules["MinkowskiEngine.utils"] = utils
+    return me

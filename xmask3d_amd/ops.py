@@ -1,0 +1,290 @@
+"""Tensor-level wrappers over the C ABI (include/xm3d.h).
+
+torch is used for device memory and streams only; every computation below is
+a HIP kernel of libxm3d_hip.so launched on torch's current stream.  No CPU
+fallbacks: tensors must live on a ROCm device.
+"""
+from __future__ import annotations
+
+import ctypes
+
+import numpy as np
+import torch
+
+from ._lib import c_i64, c_sz, check, lib
+
+
+def _stream():
+    return ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t):
+    return ctypes.c_void_p(0) if t is None else ctypes.c_void_p(t.data_ptr())
+
+
+def _req(t, dtype, name, ndim=None):
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a tensor")
+    if not t.is_cuda:
+        raise RuntimeError(f"{name} must be a ROCm device tensor (got {t.device}); xmask3d_amd has no CPU path")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected {dtype}, got {t.dtype}")
+    if not t.is_contiguous():
+        raise RuntimeError(f"{name} tensor has to be contiguous")
+    if ndim is not None and t.dim() != ndim:
+        raise RuntimeError(f"{name}: expected {ndim} dims, got {tuple(t.shape)}")
+    return t
+
+
+def _workspace(nbytes, device):
+    return torch.empty(max(int(nbytes), 256), dtype=torch.uint8, device=device)
+
+
+# ---------------------------------------------------------------- voxelisation
+def voxelize(xyz: torch.Tensor, matrix) -> tuple:
+    """xyz (n,3) f64 device, matrix 4x4 (host) -> (grid (Nv,3) i32, inds (Nv,) i64, inverse (n,) i64)."""
+    _req(xyz, torch.float64, "xyz", 2)
+    n = xyz.shape[0]
+    T = np.ascontiguousarray(np.asarray(matrix, dtype=np.float64).reshape(4, 4))
+    need = c_sz(0)
+    check(lib().xm3d_voxelize_ws_bytes(n, ctypes.byref(need)), "xm3d_voxelize_ws_bytes")
+    ws = _workspace(need.value, xyz.device)
+    grid = torch.empty((n, 3), dtype=torch.int32, device=xyz.device)
+    inds = torch.empty(n, dtype=torch.int64, device=xyz.device)
+    inv = torch.empty(n, dtype=torch.int64, device=xyz.device)
+    nu = c_i64(0)
+    check(lib().xm3d_voxelize(_ptr(xyz), n, T.ctypes.data_as(ctypes.c_void_p), _ptr(grid), _ptr(inds), _ptr(inv),
+                              ctypes.byref(nu), _ptr(ws), ws.numel(), _stream()), "xm3d_voxelize")
+    return grid[: nu.value], inds[: nu.value], inv
+
+
+def fnv_keys(grid: torch.Tensor) -> torch.Tensor:
+    _req(grid, torch.int32, "grid", 2)
+    keys = torch.empty(grid.shape[0], dtype=torch.int64, device=grid.device)  # raw u64 bits
+    check(lib().xm3d_fnv_keys(_ptr(grid), grid.shape[0], _ptr(keys), _stream()), "xm3d_fnv_keys")
+    return keys
+
+
+# ---------------------------------------------------------------- coordinate manager
+def _pow2_cap(n):
+    cap = 16
+    while cap < 2 * n:
+        cap *= 2
+    return cap
+
+
+class CoordinateManager:
+    """Per-forward cache of coordinate sets, hashes and neighbour tables, keyed like
+    MinkowskiEngine's coordinate manager so every conv with the same
+    (tensor_stride_in, tensor_stride_out, kernel_size, transposed) shares one table,
+    and both MinkUNets running on the same `sinput` share everything."""
+
+    def __init__(self, coords: torch.Tensor):
+        _req(coords, torch.int32, "coordinates", 2)
+        if coords.shape[1] != 4:
+            raise RuntimeError("coordinates must be (N, 4) int32 rows [batch, x, y, z]")
+        self.device = coords.device
+        self._coords = {1: coords}
+        self._hash = {}
+        self._maps = {}
+        self._order = {}
+        self._inv = {}
+
+    def _ws(self, n):
+        need = c_sz(0)
+        check(lib().xm3d_stride_ws_bytes(n, ctypes.byref(need)), "xm3d_stride_ws_bytes")
+        return _workspace(need.value, self.device)
+
+    def coords(self, ts: int) -> torch.Tensor:
+        if ts not in self._coords:
+            src = self.coords(ts // 2) if ts > 2 else self._coords[1]
+            n = src.shape[0]
+            out = torch.empty((n, 4), dtype=torch.int32, device=self.device)
+            ws = self._ws(n)
+            cnt = c_i64(0)
+            check(lib().xm3d_coords_stride(_ptr(src), n, ts, _ptr(out), ctypes.byref(cnt), _ptr(ws), ws.numel(), _stream()),
+                  "xm3d_coords_stride")
+            self._coords[ts] = out[: cnt.value]
+        return self._coords[ts]
+
+    def num(self, ts):
+        return self.coords(ts).shape[0]
+
+    def order(self, ts: int):
+        """Spatially sorted processing order (None when rows are already sorted, i.e. ts > 1)."""
+        if ts != 1:
+            return None
+        if ts not in self._order:
+            c = self._coords[1]
+            n = c.shape[0]
+            order = torch.empty(n, dtype=torch.int32, device=self.device)
+            ws = self._ws(n)
+            nu = c_i64(0)
+            check(lib().xm3d_coords_order(_ptr(c), n, _ptr(order), ctypes.byref(nu), _ptr(ws), ws.numel(), _stream()),
+                  "xm3d_coords_order")
+            if nu.value != n:
+                raise RuntimeError(f"SparseTensor coordinates must be unique ({n - nu.value} duplicates); "
+                                   "the reference always passes voxelised (deduplicated) coordinates")
+            self._order[ts] = order
+        return self._order[ts]
+
+    def hash(self, ts: int):
+        if ts not in self._hash:
+            c = self.coords(ts)
+            cap = _pow2_cap(c.shape[0])
+            tk = torch.empty(cap, dtype=torch.int64, device=self.device)
+            tv = torch.empty(cap, dtype=torch.int32, device=self.device)
+            check(lib().xm3d_hash_build(_ptr(c), c.shape[0], _ptr(tk), _ptr(tv), cap, _stream()), "xm3d_hash_build")
+            self._hash[ts] = (tk, tv, cap)
+        return self._hash[ts]
+
+    def kernel_map(self, ts_in: int, ts_out: int, ksize: int, transposed: bool = False) -> torch.Tensor:
+        """(K, n_out) int32 neighbour table; -1 marks holes."""
+        key = (ts_in, ts_out, ksize, transposed)
+        if key not in self._maps:
+            out_c = self.coords(ts_out)
+            tk, tv, cap = self.hash(ts_in)
+            n_out = out_c.shape[0]
+            K = ksize ** 3
+            nbr = torch.empty((K, n_out), dtype=torch.int32, device=self.device)
+            if transposed:
+                step, sign = ts_out, -1
+            else:
+                step, sign = ts_in, 1
+            check(lib().xm3d_kernel_map(_ptr(out_c), n_out, _ptr(tk), _ptr(tv), cap, ksize, step, sign, _ptr(nbr), _stream()),
+                  "xm3d_kernel_map")
+            self._maps[key] = nbr
+        return self._maps[key]
+
+    def inverse_map(self, ts_in, ts_out, ksize, transposed=False):
+        """(K, n_in) table with nbr_t[k, i] = o  <=>  nbr[k, o] = i (for dgrad)."""
+        key = (ts_in, ts_out, ksize, transposed)
+        if key not in self._inv:
+            nbr = self.kernel_map(*key)
+            n_in = self.num(ts_in)
+            K, n_out = nbr.shape
+            nbr_t = torch.empty((K, n_in), dtype=torch.int32, device=self.device)
+            check(lib().xm3d_kernel_map_invert(_ptr(nbr), K, n_out, n_in, _ptr(nbr_t), _stream()), "xm3d_kernel_map_invert")
+            self._inv[key] = nbr_t
+        return self._inv[key]
+
+    def check(self):
+        check(lib().xm3d_check_flag(), "coordinate manager")
+
+
+# ---------------------------------------------------------------- sparse conv
+ALGO_AUTO, ALGO_SCALAR, ALGO_MFMA = 0, 1, 2
+
+
+def pack_weight(kernel: torch.Tensor) -> torch.Tensor:
+    """(K,Cin,Cout) f32 -> MFMA fragment layout (same numel)."""
+    _req(kernel, torch.float32, "kernel", 3)
+    out = torch.empty_like(kernel)
+    K, cin, cout = kernel.shape
+    check(lib().xm3d_spconv_pack_weight(_ptr(kernel), K, cin, cout, _ptr(out), _stream()), "xm3d_spconv_pack_weight")
+    return out
+
+
+def mfma_eligible(cin, cout):
+    return cin % 32 == 0 and cout % 32 == 0
+
+
+def spconv_fwd(feats, kernel, nbr, n_out, order=None, scale=None, shift=None, residual=None, relu=False,
+               algo=ALGO_AUTO, packed=None):
+    """out (n_out, Cout) = epi(sum_k feats[nbr[k]] @ kernel[k]).  `packed` = pack_weight(kernel) cache."""
+    _req(feats, torch.float32, "features", 2)
+    _req(kernel, torch.float32, "kernel", 3)
+    K, cin, cout = kernel.shape
+    if feats.shape[1] != cin:
+        raise RuntimeError(f"feature width {feats.shape[1]} != kernel Cin {cin}")
+    if nbr is not None:
+        _req(nbr, torch.int32, "nbr", 2)
+        if tuple(nbr.shape) != (K, n_out):
+            raise RuntimeError(f"nbr shape {tuple(nbr.shape)} != ({K}, {n_out})")
+    for t, nm, ln in ((scale, "scale", cout), (shift, "shift", cout)):
+        if t is not None:
+            _req(t, torch.float32, nm, 1)
+            assert t.numel() == ln
+    if residual is not None:
+        _req(residual, torch.float32, "residual", 2)
+        assert tuple(residual.shape) == (n_out, cout)
+    if order is not None:
+        _req(order, torch.int32, "order", 1)
+        assert order.numel() == n_out
+    if algo == ALGO_AUTO:
+        algo = ALGO_MFMA if mfma_eligible(cin, cout) else ALGO_SCALAR
+    w = kernel
+    if algo == ALGO_MFMA:
+        w = packed if packed is not None else pack_weight(kernel)
+    out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    check(lib().xm3d_spconv_fwd(_ptr(feats), feats.shape[0], cin, _ptr(w), K, cout, _ptr(nbr), _ptr(order), n_out,
+                                _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out), algo, _stream()),
+          "xm3d_spconv_fwd")
+    return out
+
+
+def bn_stats(x):
+    """per-channel (sum, sumsq) in f64 over rows of an (n,c) f32 matrix."""
+    _req(x, torch.float32, "x", 2)
+    s = torch.empty(2 * x.shape[1], dtype=torch.float64, device=x.device)
+    check(lib().xm3d_bn_stats(_ptr(x), x.shape[0], x.shape[1], _ptr(s), _stream()), "xm3d_bn_stats")
+    return s[: x.shape[1]], s[x.shape[1]:]
+
+
+def affine_act(x, scale=None, shift=None, residual=None, relu=False, out=None):
+    _req(x, torch.float32, "x", 2)
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().xm3d_affine_act(_ptr(x), x.shape[0], x.shape[1], _ptr(scale), _ptr(shift), _ptr(residual),
+                                int(bool(relu)), _ptr(out), _stream()), "xm3d_affine_act")
+    return out
+
+
+# ---------------------------------------------------------------- deformable attention
+def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
+    _req(value, torch.float32, "value", 4)
+    _req(spatial_shapes, torch.int64, "spatial_shapes", 2)
+    _req(level_start_index, torch.int64, "level_start_index", 1)
+    _req(sampling_loc, torch.float32, "sampling_loc", 6)
+    _req(attn_weight, torch.float32, "attn_weight", 5)
+    B, S, H, D = value.shape
+    _, Lq, _, L, P, _ = sampling_loc.shape
+    out = torch.empty((B, Lq, H * D), dtype=torch.float32, device=value.device)
+    check(lib().xm3d_msda_forward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(sampling_loc),
+                                  _ptr(attn_weight), B, S, H, D, L, Lq, P, _ptr(out), _stream()), "xm3d_msda_forward")
+    return out
+
+
+def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output):
+    _req(value, torch.float32, "value", 4)
+    _req(spatial_shapes, torch.int64, "spatial_shapes", 2)
+    _req(level_start_index, torch.int64, "level_start_index", 1)
+    _req(sampling_loc, torch.float32, "sampling_loc", 6)
+    _req(attn_weight, torch.float32, "attn_weight", 5)
+    _req(grad_output, torch.float32, "grad_output")
+    B, S, H, D = value.shape
+    _, Lq, _, L, P, _ = sampling_loc.shape
+    gv = torch.zeros_like(value)
+    gl = torch.zeros_like(sampling_loc)
+    ga = torch.zeros_like(attn_weight)
+    check(lib().xm3d_msda_backward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(sampling_loc),
+                                   _ptr(attn_weight), _ptr(grad_output), B, S, H, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga),
+                                   _stream()), "xm3d_msda_backward")
+    return gv, gl, ga
+
+
+# ---------------------------------------------------------------- 2D->3D fusion
+def mask_point_fuse(masks_u8, x_label, y_label, embed):
+    """masks (Q,H,W) uint8, x/y (n,) i64, embed (Q,C) f32 -> (feat2d (n,C), count (n,) i32)."""
+    _req(masks_u8, torch.uint8, "masks", 3)
+    _req(x_label, torch.int64, "x_label", 1)
+    _req(y_label, torch.int64, "y_label", 1)
+    _req(embed, torch.float32, "embed", 2)
+    Q, Hm, Wm = masks_u8.shape
+    n = x_label.numel()
+    C = embed.shape[1]
+    feat = torch.empty((n, C), dtype=torch.float32, device=embed.device)
+    cnt = torch.empty(n, dtype=torch.int32, device=embed.device)
+    check(lib().xm3d_mask_point_fuse(_ptr(masks_u8), Q, Hm, Wm, _ptr(x_label), _ptr(y_label), n, _ptr(embed), C, _ptr(feat),
+                                     _ptr(cnt), _stream()), "xm3d_mask_point_fuse")
+    return feat, cnt
