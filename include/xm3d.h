@@ -104,6 +104,21 @@ int xm3d_spconv_fwd(const float* in, int64_t n_in, int32_t cin, const float* W, 
                     const int32_t* nbr, const int32_t* order, int64_t n_out, const float* scale,
                     const float* shift, const float* residual, int32_t relu, float* out, int32_t algo,
                     void* stream);
+/* Tiled rulebook (algo 3): compacts a neighbour table once per kernel map into per-workgroup
+ * pair lists shared by every conv on that map.  Row tile b = 256 consecutive rows of `order`;
+ * tsrc/tdst[(b*K + k)*256 + j] = input row / local output row of the j-th valid pair of
+ * (b, k), tcnt[b*K + k] = number of pairs.  Buffers: tsrc i32 and tdst u8 of ntiles*K*256
+ * entries, tcnt i32 of ntiles*K, ntiles = ceil(n_out/256).  nbr NULL = K=1 identity map.
+ * xm3d_spconv_fwd_tiles then computes the same result as xm3d_spconv_fwd(algo 2) from those
+ * lists (Wp = packed weights; Cin, Cout multiples of 32).  ksplit > 1 spreads the kernel offsets
+ * of one row tile over ksplit workgroups (small grids): partial sums go to `slab`
+ * (ksplit*n_out*cout f32) and are reduced in fixed order with the epilogue fused (deterministic). */
+int xm3d_rulebook_tiles(const int32_t* nbr, const int32_t* order, int64_t n_out, int32_t K, int32_t* tsrc,
+                        uint8_t* tdst, int32_t* tcnt, void* stream);
+int xm3d_spconv_fwd_tiles(const float* in, int64_t n_in, int32_t cin, const float* Wp, int32_t K, int32_t cout,
+                          const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order,
+                          int64_t n_out, const float* scale, const float* shift, const float* residual,
+                          int32_t relu, float* out, int32_t ksplit, float* slab, void* stream);
 /* Pre-pack W (K,Cin,Cout) into the MFMA B-fragment layout used by algo 2 (same byte size). */
 int xm3d_spconv_pack_weight(const float* W, int32_t K, int32_t cin, int32_t cout, float* Wp, void* stream);
 /* dgrad: gin[i,:] = sum over (k,o) with nbr[k,o]==i of gout[o,:] @ W[k]^T, computed as a

@@ -38,14 +38,35 @@ def test_conv_kernels_match_oracle(dev, cin, cout, ks, n):
     scale, shift, res = torch.rand(cout) + 0.5, torch.randn(cout), torch.randn(N, cout)
     ref_plain = so.spconv(f.double(), W.double(), nbr.cpu().numpy()).float()
     ref_epi = torch.relu(ref_plain * scale + shift + res)
-    algos = [ops.ALGO_SCALAR] + ([ops.ALGO_MFMA] if ops.mfma_eligible(cin, cout) else [])
+    algos = [ops.ALGO_SCALAR] + ([ops.ALGO_MFMA, ops.ALGO_TILES] if ops.mfma_eligible(cin, cout) else [])
     for algo in algos:
         for order in (None, cm.order(1)):
-            out = ops.spconv_fwd(f.to(dev), W.to(dev), nbr, N, order=order, algo=algo)
+            if algo == ops.ALGO_TILES and order is None:
+                continue  # the tiled rulebook is built for the manager's processing order
+            tiles = cm.tiles(1, 1, ks) if algo == ops.ALGO_TILES else None
+            out = ops.spconv_fwd(f.to(dev), W.to(dev), nbr, N, order=order, algo=algo, tiles=tiles)
             assert _rel(out.cpu(), ref_plain) < 2e-5, (algo, order is None)
             out = ops.spconv_fwd(f.to(dev), W.to(dev), nbr, N, order=order, scale=scale.to(dev), shift=shift.to(dev),
-                                 residual=res.to(dev), relu=True, algo=algo)
+                                 residual=res.to(dev), relu=True, algo=algo, tiles=tiles)
             assert _rel(out.cpu(), ref_epi) < 2e-5, (algo, order is None)
+
+
+def test_split_k_is_deterministic_and_matches(dev):
+    from xmask3d_amd import ops
+
+    torch.manual_seed(9)
+    c = _coords(900, 3, hi=14)
+    N = len(c)
+    cm = ops.CoordinateManager(torch.from_numpy(c).to(dev))
+    nbr, tiles = cm.kernel_map(1, 1, 3), cm.tiles(1, 1, 3)
+    W, f = (torch.randn(27, 256, 64) * 0.05).to(dev), torch.randn(N, 256).to(dev)
+    sc, sh = (torch.rand(64) + 0.5).to(dev), torch.randn(64).to(dev)
+    ref = torch.relu(so.spconv(f.cpu().double(), W.cpu().double(), nbr.cpu().numpy()).float() * sc.cpu() + sh.cpu())
+    outs = [ops.spconv_fwd(f, W, nbr, N, order=cm.order(1), scale=sc, shift=sh, relu=True, tiles=tiles, ksplit=ks)
+            for ks in (1, 2, 5, 27, 27)]
+    for o in outs:
+        assert _rel(o.cpu(), ref) < 2e-5
+    assert torch.equal(outs[3], outs[4])  # same split -> bitwise identical
 
 
 def test_strided_and_transposed_conv(dev):

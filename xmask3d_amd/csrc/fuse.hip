@@ -15,7 +15,12 @@ __global__ void k_mask_point_fuse(const uint8_t* __restrict__ masks, int Q, int 
     if (p >= n) return;
     const int64_t r = xr[p], c = yc[p];
     const bool ok = r >= 0 && r < Hm && c >= 0 && c < Wm;
-    // lanes test queries lane, lane+64, ... ; ballots give the covering set (ascending q = reference order)
+    // lanes test queries lane, lane+64, ... ; ballots (all 64 lanes active) give the covering set; a lane owns the
+    // channel quads lane, lane+64, ... (C <= 1024) and adds the embeddings in ascending q = the reference's order
+    constexpr int MAXJ = 4;
+    float4 acc[MAXJ];
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) acc[j] = make_float4(0.f, 0.f, 0.f, 0.f);
     int cnt = 0;
     const int C4 = C / 4;
     for (int q0 = 0; q0 < Q; q0 += 64) {
@@ -23,23 +28,28 @@ __global__ void k_mask_point_fuse(const uint8_t* __restrict__ masks, int Q, int 
         const bool hit = ok && q < Q && masks[(int64_t(q) * Hm + r) * Wm + c] != 0;
         unsigned long long m = __ballot(hit);
         cnt += __popcll(m);
-    }
-    for (int c4 = lane; c4 < C4; c4 += 64) {
-        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-        for (int q0 = 0; q0 < Q; q0 += 64) {
-            const int q = q0 + lane;
-            const bool hit = ok && q < Q && masks[(int64_t(q) * Hm + r) * Wm + c] != 0;
-            unsigned long long m = __ballot(hit);
-            while (m) {
-                const int b = __ffsll((long long)m) - 1;
-                m &= m - 1;
-                const float4 e = *reinterpret_cast<const float4*>(embed + int64_t(q0 + b) * C + c4 * 4);
-                acc.x += e.x; acc.y += e.y; acc.z += e.z; acc.w += e.w;
+        while (m) {
+            const int b = __ffsll((long long)m) - 1;
+            m &= m - 1;
+#pragma unroll
+            for (int j = 0; j < MAXJ; ++j) {
+                const int c4 = lane + 64 * j;
+                if (c4 < C4) {
+                    const float4 e = *reinterpret_cast<const float4*>(embed + int64_t(q0 + b) * C + c4 * 4);
+                    acc[j].x += e.x; acc[j].y += e.y; acc[j].z += e.z; acc[j].w += e.w;
+                }
             }
         }
-        const float d = cnt > 0 ? float(cnt) : 1e-5f;  // the reference divides by 1e-5 where no mask covers
-        acc.x /= d; acc.y /= d; acc.z /= d; acc.w /= d;
-        *reinterpret_cast<float4*>(feat2d + p * C + c4 * 4) = acc;
+    }
+    const float d = cnt > 0 ? float(cnt) : 1e-5f;  // the reference divides by 1e-5 where no mask covers
+#pragma unroll
+    for (int j = 0; j < MAXJ; ++j) {
+        const int c4 = lane + 64 * j;
+        if (c4 < C4) {
+            float4 v = acc[j];
+            v.x /= d; v.y /= d; v.z /= d; v.w /= d;
+            *reinterpret_cast<float4*>(feat2d + p * C + c4 * 4) = v;
+        }
     }
     if (lane == 0) count[p] = cnt;
 }
@@ -51,7 +61,8 @@ using namespace xm3d;
 extern "C" int xm3d_mask_point_fuse(const uint8_t* masks, int32_t Q, int32_t Hm, int32_t Wm, const int64_t* x,
                                     const int64_t* y, int64_t n, const float* embed, int32_t C, float* feat2d,
                                     int32_t* count, void* stream) {
-    XM3D_REQUIRE(Q >= 0 && Hm >= 1 && Wm >= 1 && n >= 0 && C >= 4 && C % 4 == 0, "mask_point_fuse: bad sizes (C %% 4 == 0)");
+    XM3D_REQUIRE(Q >= 0 && Hm >= 1 && Wm >= 1 && n >= 0 && C >= 4 && C % 4 == 0 && C <= 1024,
+                 "mask_point_fuse: bad sizes (C %% 4 == 0, C <= 1024)");
     if (n == 0) return XM3D_OK;
     XM3D_REQUIRE((Q == 0 || (masks && embed)) && x && y && feat2d && count, "mask_point_fuse: null pointer");
     XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(embed) | reinterpret_cast<uintptr_t>(feat2d)) & 15) == 0,

@@ -188,6 +188,229 @@ __global__ __launch_bounds__(256, 2) void k_spconv_mfma(const float* __restrict_
     }
 }
 
+// ------------------------------------------------------------------ tiled rulebook + MFMA kernel v2 (algo 3)
+// The neighbour table is compacted ONCE per kernel map into per-workgroup pair lists (shared by every conv
+// that uses the map, 8-22 layers per level in the MinkUNets): for row tile b (256 rows in processing order)
+// and offset k, tsrc/tdst[(b*K + k)*256 + j] hold the input row / local output row of the j-th valid pair and
+// tcnt[b*K + k] their number.  The conv kernel then has no ballots and knows all its work up front:
+//   * pairs are packed at WORKGROUP level (ceil(cnt/16) MFMA tiles dealt round-robin to the 4 waves)
+//   * weights for step s+1 are fetched into registers while step s computes, written to the other LDS
+//     buffer after the MFMAs: one barrier per (offset, channel-chunk) step
+//   * channel chunk = 16*ST input channels (ST = 2, 4 or 6 -> 32/64/96-deep steps)
+constexpr int TROWS = 256;
+
+__global__ __launch_bounds__(256) void k_build_tiles(const int32_t* __restrict__ nbr, const int32_t* __restrict__ order,
+                                                     int64_t n_out, int K, int32_t* __restrict__ tsrc,
+                                                     uint8_t* __restrict__ tdst, int32_t* __restrict__ tcnt) {
+    __shared__ int wcnt[4];
+    const int tile = blockIdx.x, k = blockIdx.y;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t slot = int64_t(tile) * TROWS + threadIdx.x;
+    int v = -1;
+    if (slot < n_out) {
+        const int64_t row = order ? order[slot] : slot;
+        v = nbr ? nbr[int64_t(k) * n_out + row] : int(row);
+    }
+    const unsigned long long m = __ballot(v >= 0);
+    if (lane == 0) wcnt[wave] = __popcll(m);
+    __syncthreads();
+    int base = 0;
+    for (int w = 0; w < wave; ++w) base += wcnt[w];
+    const int64_t off = (int64_t(tile) * K + k) * TROWS;
+    if (v >= 0) {
+        const int j = base + __popcll(m & ((1ull << lane) - 1ull));
+        tsrc[off + j] = v;
+        tdst[off + j] = uint8_t(threadIdx.x);
+    }
+    if (threadIdx.x == 0) tcnt[int64_t(tile) * K + k] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
+}
+
+template <int ST_>
+struct __attribute__((aligned(16))) TileLds {
+    float acc[TROWS][ACC_LD];
+    float w[2][ST_ * NT * 256];
+    int cnt[128];  // pairs per offset of this tile (K <= 125)
+};
+
+// Per-wave software pipeline over the wave's own tile sequence (which spans steps):
+//   stage A: pair indices (tsrc/tdst) of tile i+2      stage B: row gathers of tile i+1      stage C: MFMAs of tile i
+// so the count -> index -> gather chain of dependent L2 round trips is off the critical path.
+template <int ST_>
+__global__ __launch_bounds__(256, 2) void k_spconv_tiles(const float* __restrict__ in, int cin, const float* __restrict__ Wp,
+                                                          int K, int cout, const int32_t* __restrict__ tsrc,
+                                                          const uint8_t* __restrict__ tdst, const int32_t* __restrict__ tcnt,
+                                                          const int32_t* __restrict__ order, int64_t n_out,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ residual, int relu,
+                                                          float* __restrict__ out, int ksplit, float* __restrict__ slab) {
+    __shared__ TileLds<ST_> lds;
+    constexpr int NW = ST_ * NT / 4;  // float4 weight loads per thread per step
+    const int kz = blockIdx.z;                              // split-K: this workgroup handles offsets kz, kz+ksplit, ...
+    const int nk = (K - kz + ksplit - 1) / ksplit;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int p16 = lane & 15, kq = lane >> 4;
+    const int tile = blockIdx.x;
+    const int ct0 = blockIdx.y * CT;
+    const int NS = cout / 16, CS = cin / 16;
+    const int nchunk = cin / (16 * ST_);
+    const int nsteps = nk * nchunk;
+    const int64_t tbase = int64_t(tile) * K;
+
+    for (int c = tid; c < TROWS * ACC_LD; c += 256) (&lds.acc[0][0])[c] = 0.f;
+    if (tid < nk) lds.cnt[tid] = tcnt[tbase + kz + tid * ksplit];
+
+    f32x4 wreg[NW];
+    auto load_w = [&](int step) {
+        const int kk = step / nchunk, cc = step - kk * nchunk;
+        const int k = kz + kk * ksplit;
+#pragma unroll
+        for (int j = 0; j < NW; ++j) {
+            const int f = j * 256 + tid;  // float4 index inside the chunk: ST segments of 128 float4
+            const int s = f >> 7, within = f & 127;
+            const int64_t g = ((int64_t(k) * CS + cc * ST_ + s) * NS + ct0 / 16) * 256 + within * 4;
+            wreg[j] = *reinterpret_cast<const f32x4*>(Wp + g);
+        }
+    };
+    auto store_w = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < NW; ++j) *reinterpret_cast<f32x4*>(&lds.w[buf][(j * 256 + tid) * 4]) = wreg[j];
+    };
+    if (nsteps > 0) {
+        load_w(0);
+        store_w(0);
+    }
+    __syncthreads();
+
+    // tile iterator of this wave: (step, t) with t = wave, wave+4, ... < ceil(cnt[k]/16); step == nsteps means "none"
+    struct Ref {
+        int step, t;
+    };
+    auto advance = [&](Ref r) {
+        r.t += WAVES;
+        while (r.step < nsteps) {
+            const int kk = r.step / nchunk;
+            if (r.t * 16 < lds.cnt[kk]) break;
+            ++r.step;
+            r.t = wave;
+        }
+        return r;
+    };
+    auto load_idx = [&](Ref r, int& srow, int& drow) {
+        srow = -1;
+        drow = -1;
+        if (r.step < nsteps) {
+            const int kk = r.step / nchunk;
+            const int p = r.t * 16 + p16;
+            if (p < lds.cnt[kk]) {
+                const int64_t o = (tbase + kz + kk * ksplit) * TROWS + p;
+                srow = tsrc[o];
+                drow = int(tdst[o]);
+            }
+        }
+    };
+    auto gather = [&](Ref r, int srow, f32x4 (&x)[ST_]) {
+        const int cc = (r.step < nsteps) ? r.step % nchunk : 0;
+#pragma unroll
+        for (int s = 0; s < ST_; ++s) {
+            x[s] = f32x4{0.f, 0.f, 0.f, 0.f};
+            if (srow >= 0) x[s] = *reinterpret_cast<const f32x4*>(in + int64_t(srow) * cin + cc * (16 * ST_) + s * 16 + kq * 4);
+        }
+    };
+
+    Ref r0 = advance(Ref{0, wave - WAVES});
+    Ref r1 = advance(r0);
+    int s0, d0, s1, d1;
+    load_idx(r0, s0, d0);
+    load_idx(r1, s1, d1);
+    f32x4 x0[ST_], x1[ST_];
+    gather(r0, s0, x0);
+
+    int cur = 0;
+    for (int step = 0; step < nsteps; ++step) {
+        if (step + 1 < nsteps) load_w(step + 1);
+        while (r0.step == step) {
+            const Ref r2 = advance(r1);
+            int s2, d2;
+            load_idx(r2, s2, d2);   // stage A for tile i+2
+            gather(r1, s1, x1);     // stage B for tile i+1
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {  // stage C
+                f32x4 d = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int s = 0; s < ST_; ++s) {
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(&lds.w[cur][(s * NT + n) * 256 + lane * 4]);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x0[s][0], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x0[s][1], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x0[s][2], d, 0, 0, 0);
+                    d = __builtin_amdgcn_mfma_f32_16x16x4f32(w[3], x0[s][3], d, 0, 0, 0);
+                }
+                if (d0 >= 0) {
+                    f32x4* a = reinterpret_cast<f32x4*>(&lds.acc[d0][n * 16 + kq * 4]);
+                    f32x4 c = *a;
+                    c += d;
+                    *a = c;
+                }
+            }
+#pragma unroll
+            for (int s = 0; s < ST_; ++s) x0[s] = x1[s];
+            d0 = d1;
+            s1 = s2;
+            d1 = d2;
+            r0 = r1;
+            r1 = r2;
+        }
+        if (step + 1 < nsteps) store_w(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // epilogue: 8 lanes x float4 per 32-channel row, 32 rows per pass
+    const int rsub = tid >> 3, c4 = (tid & 7) * 4;
+    for (int r = 0; r < TROWS; r += 32) {
+        const int lr = r + rsub;
+        const int64_t sl = int64_t(tile) * TROWS + lr;
+        if (sl >= n_out) continue;
+        const int64_t grow = order ? order[sl] : sl;
+        f32x4 v = *reinterpret_cast<const f32x4*>(&lds.acc[lr][c4]);
+        const int c = ct0 + c4;
+        if (ksplit > 1) {  // raw partial sum; k_slab_reduce applies the epilogue
+            *reinterpret_cast<f32x4*>(slab + (int64_t(kz) * n_out + grow) * cout + c) = v;
+            continue;
+        }
+        if (scale) v *= *reinterpret_cast<const f32x4*>(scale + c);
+        if (shift) v += *reinterpret_cast<const f32x4*>(shift + c);
+        if (residual) v += *reinterpret_cast<const f32x4*>(residual + grow * cout + c);
+        if (relu) {
+            v[0] = fmaxf(v[0], 0.f);
+            v[1] = fmaxf(v[1], 0.f);
+            v[2] = fmaxf(v[2], 0.f);
+            v[3] = fmaxf(v[3], 0.f);
+        }
+        *reinterpret_cast<f32x4*>(out + grow * cout + c) = v;
+    }
+}
+
+// out = epi(sum_z slab[z]) in fixed z order (bitwise reproducible)
+__global__ void k_slab_reduce(const float* __restrict__ slab, int ksplit, int64_t n4, int64_t stride4, int c,
+                              const float* __restrict__ scale, const float* __restrict__ shift,
+                              const float* __restrict__ residual, int relu, float* __restrict__ out) {
+    const int64_t gs = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n4; e += gs) {
+        f32x4 v = reinterpret_cast<const f32x4*>(slab)[e];
+        for (int z = 1; z < ksplit; ++z) v += reinterpret_cast<const f32x4*>(slab)[z * stride4 + e];
+        const int ch = int((e * 4) % c);
+        if (scale) v *= *reinterpret_cast<const f32x4*>(scale + ch);
+        if (shift) v += *reinterpret_cast<const f32x4*>(shift + ch);
+        if (residual) v += reinterpret_cast<const f32x4*>(residual)[e];
+        if (relu) {
+            v[0] = fmaxf(v[0], 0.f);
+            v[1] = fmaxf(v[1], 0.f);
+            v[2] = fmaxf(v[2], 0.f);
+            v[3] = fmaxf(v[3], 0.f);
+        }
+        reinterpret_cast<f32x4*>(out)[e] = v;
+    }
+}
+
 // ------------------------------------------------------------------ weight gradient
 // gW[k][ci][co] = sum_o in[nbr[k,o]][ci] * gout[o][co].
 // grid = (row chunks, (cin/32)*(cout/32) tiles, K); each wave owns one 32x32 tile of gW[k] and a slice of
@@ -340,6 +563,51 @@ extern "C" int xm3d_spconv_bwd_weight(const float* in, int64_t n_in, int32_t cin
                            nbr, n_out, gW);
     } else {
         hipLaunchKernelGGL(k_spconv_wgrad_scalar, dim3(chunks, K), dim3(256), 0, s, in, cin, gout, cout, nbr, n_out, gW);
+    }
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+extern "C" int xm3d_rulebook_tiles(const int32_t* nbr, const int32_t* order, int64_t n_out, int32_t K, int32_t* tsrc,
+                                   uint8_t* tdst, int32_t* tcnt, void* stream) {
+    XM3D_REQUIRE(n_out >= 0 && K >= 1, "rulebook_tiles: bad sizes");
+    XM3D_REQUIRE(nbr || K == 1, "rulebook_tiles: nbr may be NULL only for K=1 identity maps");
+    if (n_out == 0) return XM3D_OK;
+    XM3D_REQUIRE(tsrc && tdst && tcnt, "rulebook_tiles: null output");
+    const int ntiles = int((n_out + TROWS - 1) / TROWS);
+    hipLaunchKernelGGL(k_build_tiles, dim3(ntiles, K), dim3(256), 0, as_stream(stream), nbr, order, n_out, K, tsrc, tdst, tcnt);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+extern "C" int xm3d_spconv_fwd_tiles(const float* in, int64_t n_in, int32_t cin, const float* Wp, int32_t K, int32_t cout,
+                                     const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order,
+                                     int64_t n_out, const float* scale, const float* shift, const float* residual,
+                                     int32_t relu, float* out, int32_t ksplit, float* slab, void* stream) {
+    XM3D_REQUIRE(n_in >= 0 && n_out >= 0 && K >= 1, "spconv_fwd_tiles: bad sizes");
+    XM3D_REQUIRE(cin % 32 == 0 && cout % CT == 0 && cin >= 32, "spconv_fwd_tiles: cin=%d cout=%d must be multiples of 32", cin, cout);
+    if (n_out == 0) return XM3D_OK;
+    XM3D_REQUIRE(in && Wp && tsrc && tdst && tcnt && out, "spconv_fwd_tiles: null pointer");
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(Wp) |
+                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0,
+                 "spconv_fwd_tiles: tensors must be 16-byte aligned");
+    XM3D_REQUIRE(ksplit >= 1 && ksplit <= K && (ksplit == 1 || slab), "spconv_fwd_tiles: ksplit=%d needs 1..K and a slab", ksplit);
+    dim3 grid((n_out + TROWS - 1) / TROWS, cout / CT, ksplit);
+    hipStream_t s = as_stream(stream);
+#define XM3D_TILES(ST_)                                                                                                 \
+    hipLaunchKernelGGL(k_spconv_tiles<ST_>, grid, dim3(256), 0, s, in, cin, Wp, K, cout, tsrc, tdst, tcnt, order, n_out, \
+                       scale, shift, residual, relu, out, ksplit, slab)
+    XM3D_REQUIRE(K <= 128, "spconv_fwd_tiles: K=%d > 128", K);
+    if (cin % 128 == 0) XM3D_TILES(8);
+    else if (cin % 96 == 0) XM3D_TILES(6);
+    else if (cin % 64 == 0) XM3D_TILES(4);
+    else XM3D_TILES(2);
+#undef XM3D_TILES
+    if (ksplit > 1) {
+        const int64_t n4 = n_out * cout / 4;
+        int64_t blocks = (n4 + 255) / 256;
+        if (blocks > 2048) blocks = 2048;
+        hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out);
     }
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;

@@ -33,9 +33,9 @@ from . import ops
 
 # ----------------------------------------------------------------------------- tensors
 class _PendingConv:
-    def __init__(self, feats, kernel3, packed, nbr, order, n_out):
+    def __init__(self, feats, kernel3, packed, nbr, order, n_out, tiles=None):
         self.feats, self.kernel3, self.packed = feats, kernel3, packed
-        self.nbr, self.order, self.n_out = nbr, order, n_out
+        self.nbr, self.order, self.n_out, self.tiles = nbr, order, n_out, tiles
         self.scale = self.shift = self.residual = None
         self.relu = False
 
@@ -44,7 +44,8 @@ class _PendingConv:
 
     def run(self):
         return ops.spconv_fwd(self.feats, self.kernel3, self.nbr, self.n_out, order=self.order, scale=self.scale,
-                              shift=self.shift, residual=self.residual, relu=self.relu, packed=self.packed)
+                              shift=self.shift, residual=self.residual, relu=self.relu, packed=self.packed,
+                              tiles=self.tiles)
 
 
 class _PendingAffine:
@@ -206,11 +207,13 @@ class _ConvBase(nn.Module):
         if not k3.is_contiguous():
             k3 = k3.contiguous()
         n_out = cm.num(ts_out)
-        if self.kernel_volume == 1 and self.stride == 1:
-            nbr = None
-        else:
+        packed = self._packed_weight(k3)
+        nbr = tiles = None
+        if packed is not None:
+            tiles = cm.tiles(ts_in, ts_out, self.kernel_size, self.transposed)
+        if not (self.kernel_volume == 1 and self.stride == 1):
             nbr = cm.kernel_map(ts_in, ts_out, self.kernel_size, self.transposed)
-        pend = _PendingConv(feats, k3, self._packed_weight(k3), nbr, cm.order(ts_out), n_out)
+        pend = _PendingConv(feats, k3, packed, nbr, cm.order(ts_out), n_out, tiles)
         if self.bias is not None:
             pend.shift = self.bias.detach().reshape(-1).contiguous()
         return SparseTensor(tensor_stride=ts_out, coordinate_manager=cm, _pending=pend)
@@ -243,7 +246,12 @@ class MinkowskiBatchNorm(nn.Module):
         bn = self.bn
         use_batch = self.training or not bn.track_running_stats
         if not use_batch:
-            scale, shift = self._scale_shift(bn.running_mean, bn.running_var)
+            key = (bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(),
+                   bn.weight._version if bn.affine else 0, bn.bias._version if bn.affine else 0)
+            if getattr(self, "_fold_key", None) != key:
+                self._fold = self._scale_shift(bn.running_mean, bn.running_var)
+                self._fold_key = key
+            scale, shift = self._fold
             p = x._pending
             if p is not None and p.can_fold_affine():
                 if p.scale is None and p.shift is None:

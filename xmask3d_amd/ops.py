@@ -89,6 +89,7 @@ class CoordinateManager:
         self._maps = {}
         self._order = {}
         self._inv = {}
+        self._tiles = {}
 
     def _ws(self, n):
         need = c_sz(0)
@@ -168,12 +169,32 @@ class CoordinateManager:
             self._inv[key] = nbr_t
         return self._inv[key]
 
+    def tiles(self, ts_in, ts_out, ksize, transposed=False, inverse=False):
+        """Tiled rulebook (tsrc i32, tdst u8, tcnt i32) of a kernel map (or of its inverse, for dgrad);
+        built once and shared by every conv on that map.  ksize=1 gives the identity map."""
+        key = (ts_in, ts_out, ksize, transposed, inverse)
+        if key not in self._tiles:
+            if inverse:
+                nbr, n_out, order = self.inverse_map(ts_in, ts_out, ksize, transposed), self.num(ts_in), self.order(ts_in)
+            else:
+                nbr = None if (ksize == 1 and ts_in == ts_out) else self.kernel_map(ts_in, ts_out, ksize, transposed)
+                n_out, order = self.num(ts_out), self.order(ts_out)
+            K = 1 if nbr is None else nbr.shape[0]
+            ntiles = (n_out + 255) // 256
+            tsrc = torch.empty(max(ntiles * K * 256, 1), dtype=torch.int32, device=self.device)
+            tdst = torch.empty(max(ntiles * K * 256, 1), dtype=torch.uint8, device=self.device)
+            tcnt = torch.empty(max(ntiles * K, 1), dtype=torch.int32, device=self.device)
+            check(lib().xm3d_rulebook_tiles(_ptr(nbr), _ptr(order), n_out, K, _ptr(tsrc), _ptr(tdst), _ptr(tcnt), _stream()),
+                  "xm3d_rulebook_tiles")
+            self._tiles[key] = (tsrc, tdst, tcnt)
+        return self._tiles[key]
+
     def check(self):
         check(lib().xm3d_check_flag(), "coordinate manager")
 
 
 # ---------------------------------------------------------------- sparse conv
-ALGO_AUTO, ALGO_SCALAR, ALGO_MFMA = 0, 1, 2
+ALGO_AUTO, ALGO_SCALAR, ALGO_MFMA, ALGO_TILES = 0, 1, 2, 3
 
 
 def pack_weight(kernel: torch.Tensor) -> torch.Tensor:
@@ -190,8 +211,9 @@ def mfma_eligible(cin, cout):
 
 
 def spconv_fwd(feats, kernel, nbr, n_out, order=None, scale=None, shift=None, residual=None, relu=False,
-               algo=ALGO_AUTO, packed=None):
-    """out (n_out, Cout) = epi(sum_k feats[nbr[k]] @ kernel[k]).  `packed` = pack_weight(kernel) cache."""
+               algo=ALGO_AUTO, packed=None, tiles=None, ksplit=None):
+    """out (n_out, Cout) = epi(sum_k feats[nbr[k]] @ kernel[k]).  `packed` = pack_weight(kernel) cache;
+    `tiles` = CoordinateManager.tiles(...) selects the tiled-rulebook MFMA kernel (algo 3)."""
     _req(feats, torch.float32, "features", 2)
     _req(kernel, torch.float32, "kernel", 3)
     K, cin, cout = kernel.shape
@@ -212,11 +234,23 @@ def spconv_fwd(feats, kernel, nbr, n_out, order=None, scale=None, shift=None, re
         _req(order, torch.int32, "order", 1)
         assert order.numel() == n_out
     if algo == ALGO_AUTO:
-        algo = ALGO_MFMA if mfma_eligible(cin, cout) else ALGO_SCALAR
+        algo = (ALGO_TILES if tiles is not None else ALGO_MFMA) if mfma_eligible(cin, cout) else ALGO_SCALAR
     w = kernel
-    if algo == ALGO_MFMA:
+    if algo in (ALGO_MFMA, ALGO_TILES):
         w = packed if packed is not None else pack_weight(kernel)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
+    if algo == ALGO_TILES:
+        if tiles is None:
+            raise RuntimeError("ALGO_TILES needs the tiled rulebook (CoordinateManager.tiles)")
+        tsrc, tdst, tcnt = tiles
+        if ksplit is None:
+            wgs = ((n_out + 255) // 256) * (cout // 32)
+            ksplit = 1 if wgs >= 256 else max(1, min(K, 768 // max(wgs, 1)))
+        slab = torch.empty((ksplit, n_out, cout), dtype=torch.float32, device=feats.device) if ksplit > 1 else None
+        check(lib().xm3d_spconv_fwd_tiles(_ptr(feats), feats.shape[0], cin, _ptr(w), K, cout, _ptr(tsrc), _ptr(tdst), _ptr(tcnt),
+                                          _ptr(order), n_out, _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)),
+                                          _ptr(out), ksplit, _ptr(slab), _stream()), "xm3d_spconv_fwd_tiles")
+        return out
     check(lib().xm3d_spconv_fwd(_ptr(feats), feats.shape[0], cin, _ptr(w), K, cout, _ptr(nbr), _ptr(order), n_out,
                                 _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out), algo, _stream()),
           "xm3d_spconv_fwd")
