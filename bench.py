@@ -1,0 +1,231 @@
+#!/usr/bin/env python3
+"""XMask3D scene inference benchmark on MI355X.
+
+python bench.py --gpus N --steps K --warmup W      (N>1: launched by torch.distributed.run, one rank per GPU)
+
+A step = one pass of the hot path over one synthetic ScanNet-shaped scene S1 (119,963
+points, 5 views of 240x320 -> 512x512): per view voxelise the visible subset (HIP), MinkUNet34C +
+MinkUNet18A (HIP sparse conv), 3D-conditioned SD-v1 VAE/UNet feature extractor, Mask2Former pixel +
+transformer decoder (HIP deformable attention), mask-CLIP ViT-L/14, 2D->3D fusion (HIP), open-vocabulary
+logits; then vote over views and fill unseen points.  Inputs are resident in HBM before the timed region.
+Weights are seeded random (no checkpoints offline); config = ScanNet B15N4.
+
+Prints ONE JSON line (rank 0).  value = scenes/s over all ranks (weak scaling: every rank runs K scenes).
+"""
+from __future__ import annotations
+
+import argparse
+import copy
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np
+import torch
+
+FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
+BF16_MFMA_PEAK_TF = 2500.0  # dense bf16
+DENSE_TFLOP_PER_VIEW_MIN = 2.83  # SURVEY.md §8d, dead compute pruned
+DENSE_TFLOP_PER_VIEW_REF = 4.79  # as the reference computes
+
+
+def log(msg):
+    if int(os.environ.get("RANK", "0")) == 0:
+        print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
+def host_threads():
+    """threads for the CPU baseline: the cores this process may run on, capped at the GPU box's per-GPU share"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(n, 16))
+
+
+def event_ms(fn, reps, stream=None):
+    """average device time of fn() over reps launches, HIP events on torch's current stream"""
+    start, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    fn()
+    torch.cuda.synchronize()
+    start.record()
+    for _ in range(reps):
+        fn()
+    end.record()
+    torch.cuda.synchronize()
+    return start.elapsed_time(end) / reps
+
+
+def spconv_roofline(dev):
+    """Roofline of the dominant hand-written kernel, k_spconv_tiles<6>, on the S1-full 96->96 k=3 layer at
+    tensor stride 1 (MinkUNet34C block8): algorithmic FLOP = 2*P*Cin*Cout, bytes = gather+scatter model."""
+    from xmask3d_amd import ops, synthetic
+
+    sc = synthetic.scene_s1()
+    T = np.diag([50.0, 50.0, 50.0, 1.0])
+    grid, inds, inv = ops.voxelize(torch.from_numpy(sc.points).to(dev), T)
+    coords = torch.cat([torch.zeros(grid.shape[0], 1, dtype=torch.int32, device=dev), grid], 1).contiguous()
+    cm = ops.CoordinateManager(coords)
+    n = coords.shape[0]
+    nbr, tiles, order = cm.kernel_map(1, 1, 3), cm.tiles(1, 1, 3), cm.order(1)
+    pairs = int((nbr >= 0).sum().item())
+    cin = cout = 96
+    g = torch.Generator(device="cpu").manual_seed(1)
+    feats = torch.randn(n, cin, generator=g).to(dev)
+    W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev)
+    packed = ops.pack_weight(W)
+    ms = event_ms(lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=packed, tiles=tiles, relu=True), 20)
+    flop = 2.0 * pairs * cin * cout
+    gs_bytes = pairs * (cin + cout) * 4 + pairs * 8 + 27 * cin * cout * 4
+    return {"kernel": "xm3d::k_spconv_tiles<6>", "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF,
+            "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None,
+            "avg_launch_us": ms * 1e3, "pairs": pairs, "voxels": n, "cin": cin, "cout": cout,
+            "gather_scatter_GBps": gs_bytes / (ms * 1e-3) / 1e9}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="dtype of the frozen dense nets (SD, CLIP)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--faithful-dead-compute", action="store_true", help="also run what the reference computes and discards")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if args.gpus != 1 or world != 1:
+            raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a ROCm device (there is no CPU fallback for the product path)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    import torch.distributed as dist
+
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+
+    import __graft_entry__
+
+    if rank == 0 and not os.path.exists(os.path.join(ROOT, "xmask3d_amd", "libxm3d_hip.so")):
+        __graft_entry__.build()
+    if world > 1:
+        dist.barrier()
+
+    from xmask3d_amd import pipeline, synthetic
+    from xmask3d_amd.config import load_cfg_from_cfg_file
+    from xmask3d_amd.xmask3d import XMASK3d
+
+    cfg = load_cfg_from_cfg_file(os.path.join(ROOT, "configs", "xmask3d_scannet_B15N4.yaml"))
+    torch.manual_seed(cfg.manual_seed)
+    torch.set_num_threads(host_threads())
+    log(f"building model (seeded random weights), host threads {host_threads()}")
+    cpu_model = XMASK3d(cfg, prune_dead_compute=not args.faithful_dead_compute).eval()
+    model = copy.deepcopy(cpu_model).to(dev).eval()
+    dense_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
+    model.set_dense_dtype(dense_dtype)
+
+    scene = synthetic.scene_s1()
+    sd = pipeline.SceneOnDevice(scene, dev)
+    voxelizer = pipeline.default_voxelizer(cfg.voxel_size, dev)
+    np.random.seed(cfg.manual_seed + rank)
+
+    def step():
+        return pipeline.infer_scene(model, sd, cfg, voxelizer)
+
+    log("model on device; warmup")
+    for i in range(args.warmup):
+        step()
+        torch.cuda.synchronize()
+        log(f"warmup step {i} done")
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        preds = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank != 0:
+        if world > 1:
+            dist.destroy_process_group()
+        return
+
+    log(f"timed {args.steps} steps in {elapsed:.3f} s")
+    n_views = len(sd.views)
+    ms_per_step = elapsed / args.steps * 1e3
+    value = world * args.steps / elapsed
+
+    # stage-level roofline of the dominant stage (dense 2D branch) + kernel-level roofline of the dominant HIP kernel
+    batch = pipeline.build_view_batch(sd, 3, voxelizer, np.diag([50.0, 50.0, 50.0, 1.0]))
+    with torch.no_grad():
+        pred_3d, cond, bs = model.encode_3d(batch["sinput"], batch["inds_reconstruct"], 1)
+        dense_ms = event_ms(lambda: model.encode_2d(batch["img"], cond), 3)
+        sparse_ms = event_ms(lambda: model.encode_3d(pipeline.build_view_batch(sd, 3, voxelizer, np.diag([50.0, 50.0, 50.0, 1.0]))["sinput"],
+                                                      batch["inds_reconstruct"], 1), 3)
+    dense_tflop = DENSE_TFLOP_PER_VIEW_REF if args.faithful_dead_compute else DENSE_TFLOP_PER_VIEW_MIN
+    dense_tflop -= 0.195  # mask-CLIP runs outside encode_2d
+    peak = BF16_MFMA_PEAK_TF if args.dtype == "bf16" else FP32_MFMA_PEAK_TF
+    log(f"dense branch {dense_ms:.1f} ms/view, sparse branch {sparse_ms:.1f} ms/view; kernel roofline")
+    roof_kernel = spconv_roofline(dev)
+    roofline = {"bound": "mfma", "achieved": dense_tflop / (dense_ms * 1e-3), "peak": peak, "unit": "TFLOP/s",
+                "frac": dense_tflop / (dense_ms * 1e-3) / peak, "traffic": None,
+                "scope": "dense 2D branch of one view (SD VAE+UNet, projections, pixel+transformer decoder), library GEMM/conv kernels",
+                "ms": dense_ms, "algorithmic_tflop": dense_tflop, "sparse3d_ms_per_view": sparse_ms,
+                "hip_kernel": roof_kernel}
+
+    cpu_baseline = None
+    if not args.no_cpu_baseline:
+        from oracle import model_oracle, voxel_oracle
+
+        log("cpu baseline (1 view through the oracle)")
+        v = 3
+        vis, rows, cols = synthetic.view_subset(scene, v)
+        pts = scene.points[vis]
+        T = np.diag([50.0, 50.0, 50.0, 1.0])
+        t1 = time.perf_counter()
+        grid, inds, inv = voxel_oracle.voxelize_with_matrix(pts, T)
+        coords = torch.from_numpy(np.concatenate([np.zeros((len(grid), 1)), grid], 1).astype(np.int32))
+        feats = torch.from_numpy((scene.colors[vis][inds] / 127.5 - 1).astype(np.float32))
+        cbatch = {"sinput": model_oracle.CpuSparseTensor(feats, coords), "img": torch.from_numpy(scene.images[v]).permute(2, 0, 1)[None],
+                  "x_label": torch.from_numpy(rows).long(), "y_label": torch.from_numpy(cols).long(),
+                  "inds_reconstruct": torch.from_numpy(inv), "captions": ("a room",),
+                  "ori_coords": torch.cat([torch.zeros(len(pts), 1), torch.from_numpy(pts).float()], 1)}
+        model_oracle.forward_cpu(cpu_model, cbatch)
+        t_view = time.perf_counter() - t1
+        cpu_baseline = {"value": 1.0 / (t_view * n_views), "unit": "scenes/s", "cores": torch.get_num_threads(), "kind": "port",
+                        "sample": f"1 of {n_views} views of S1 (view {v}, {len(pts)} points) through oracle/model_oracle.py "
+                                  f"(fp32, same weights), {t_view:.1f} s, extrapolated x{n_views}; vote/fill excluded"}
+
+    out = {
+        "metric": "ScanNet scenes/sec (infer)", "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype + " (frozen SD/CLIP nets) + f32 (sparse 3D, deformable attention, heads)", "data": "synthetic",
+        "config": {"workload": "ScanNet B15N4 inference, synthetic scene S1 (119963 pts, 5 views 240x320->512x512), batch 1 per view, "
+                               "seeded random weights", "views_per_scene": n_views, "parallelism": f"dp{world} (scene level, no collective)",
+                   "dead_compute": "as reference" if args.faithful_dead_compute else "pruned (SURVEY F7)"},
+        "roofline": roofline, "cpu_baseline": cpu_baseline,
+    }
+    print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,257 @@
+"""3D-conditioned Stable-Diffusion feature extractor + projection backbone.
+
+Mirrors, with the same attribute / parameter names so released checkpoints map 1:1:
+  * LdmExtractor                     /root/reference/models/modeling/meta_arch/ldm.py:209-571
+  * PositionalLinear, LdmImplicitCaptionerExtractor            ldm.py:574-676
+  * FeatureExtractorBackbone         /root/reference/models/modeling/backbone/feature_extractor.py:20-234
+    (its GN bottlenecks are detectron2 ``BottleneckBlock(norm="GN")``: conv{1,2,3}.weight + conv*.norm.*, shortcut.*)
+
+Differences on purpose (documented in DESIGN.md):
+  * ``prune_dead_compute`` (default True): the VAE decoder stops at the last tapped block and the UNet
+    stops before output_blocks[11]/out - the reference computes and discards them.
+    ``prune_dead_compute=False`` runs everything the reference runs.
+  * frozen SD weights never get requires_grad flipped on: only gradients w.r.t. the
+    conditioning inputs flow.
+  * the frozen text encoder's embedding of "" (``uncond_inputs``) is a registered buffer; without the
+    SD checkpoint it is filled deterministically (seed 0), like the random-init weights.
+"""
+from __future__ import annotations
+
+import math
+from collections import defaultdict
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .sd_model import AutoencoderKL, UNetModel
+
+SCALE_FACTOR = 0.18215
+# sqrt(alphas_cumprod[0]) and sqrt(1 - alphas_cumprod[0]) of the "ldm_linear" schedule
+# (models/modeling/diffusion/gaussian_diffusion.py:61-90,190-199; pinned by tests/golden/diffusion.npz)
+SQRT_AC0 = 0.9995749096490968
+SQRT_1M_AC0 = 0.029154759474226803
+
+
+class LatentDiffusion(nn.Module):
+    """Holder with the reference's attribute names: .encoder / .unet / .decoder, pixel_mean/std, uncond_inputs."""
+
+    def __init__(self):
+        super().__init__()
+        self.first_stage_model = AutoencoderKL()
+        self.unet_model = UNetModel()
+        self.image_size, self.latent_image_size, self.latent_dim = (512, 512), (64, 64), 4
+        g = torch.Generator().manual_seed(0)
+        self.register_buffer("uncond_inputs", torch.randn(1, 77, 768, generator=g) * 0.5)
+        self.register_buffer("pixel_mean", torch.tensor([0.5, 0.5, 0.5]).view(-1, 1, 1), False)
+        self.register_buffer("pixel_std", torch.tensor([0.5, 0.5, 0.5]).view(-1, 1, 1), False)
+
+    @property
+    def encoder(self):
+        return self.first_stage_model.encoder
+
+    @property
+    def decoder(self):
+        return self.first_stage_model.decoder
+
+    @property
+    def unet(self):
+        return self.unet_model
+
+
+class LdmExtractor(nn.Module):
+    def __init__(self, encoder_block_indices=(5, 7), unet_block_indices=(2, 5, 8, 11), decoder_block_indices=(2, 5),
+                 steps=(0,), prune_dead_compute=True):
+        super().__init__()
+        assert tuple(steps) == (0,), "XMask3D uses the single step t=0"
+        self.encoder_block_indices, self.unet_block_indices = tuple(encoder_block_indices), tuple(unet_block_indices)
+        self.decoder_block_indices, self.steps = tuple(decoder_block_indices), tuple(steps)
+        self.prune_dead_compute = prune_dead_compute
+        self.ldm = LatentDiffusion()
+        rng = torch.Generator().manual_seed(42)
+        self.register_buffer("shared_noise", torch.randn(1, 4, 64, 64, generator=rng))
+        for p in self.parameters():
+            p.requires_grad = False
+
+    def train(self, mode=True):  # frozen: always eval (helper.py:41-49)
+        return super().train(False)
+
+    def state_dict(self, *a, **k):  # frozen nets contribute no checkpoint keys (helper.py:38-39)
+        from collections import OrderedDict
+
+        return OrderedDict()
+
+    @property
+    def feature_dims(self):
+        enc = self.ldm.encoder
+        blocks = [b for lvl in enc.down for b in lvl.block]
+        dims = [blocks[i].in_channels for i in self.encoder_block_indices]
+        dims += [self.ldm.unet.output_blocks[i][0].channels for i in self.unet_block_indices]
+        dblocks = [b for i in reversed(range(self.ldm.decoder.num_resolutions)) for b in self.ldm.decoder.up[i].block]
+        dims += [dblocks[i].in_channels for i in self.decoder_block_indices]
+        return dims
+
+    @property
+    def feature_strides(self):
+        s = [2 ** ((i + 2) // 2 - 1) for i in self.encoder_block_indices]
+        s += [64 // (2 ** ((i + 3) // 3 - 1)) for i in self.unet_block_indices]
+        s += [8 // (2 ** ((i + 3) // 3 - 1)) for i in self.decoder_block_indices]
+        return s
+
+    @property
+    def grouped_indices(self):
+        n = len(self.encoder_block_indices) + len(self.unet_block_indices) + len(self.decoder_block_indices)
+        return [[i] for i in range(n)]
+
+    def forward(self, img, cond_inputs, cond_emb):
+        """img (B,3,512,512) in [0,1]; cond_inputs (B,77,768); cond_emb (B,1,1280) -> list of 8 feature maps."""
+        ldm = self.ldm
+        x = (img - ldm.pixel_mean.to(img.dtype)) / ldm.pixel_std.to(img.dtype)
+        moments, enc_feats = ldm.encoder(x, taps=self.encoder_block_indices)
+        moments = ldm.first_stage_model.quant_conv(moments)
+        latent = SCALE_FACTOR * moments[:, :4]  # posterior mean
+        noise = self.shared_noise.to(latent.dtype)
+        if noise.shape[2:] != latent.shape[2:]:
+            noise = F.interpolate(noise, size=latent.shape[2:], mode="bicubic", align_corners=False)
+        noisy = SQRT_AC0 * latent + SQRT_1M_AC0 * noise.expand_as(latent)
+        t = torch.zeros(latent.shape[0], dtype=torch.long, device=latent.device)
+        _, unet_feats = ldm.unet(noisy, t, cond_inputs, cond_emb=cond_emb[:, 0], taps=self.unet_block_indices,
+                                 stop_after_taps=self.prune_dead_compute)
+        z = ldm.first_stage_model.post_quant_conv(latent / SCALE_FACTOR)
+        _, dec_feats = ldm.decoder(z, taps=self.decoder_block_indices, stop_after_taps=self.prune_dead_compute)
+        return [*enc_feats, *unet_feats, *dec_feats]
+
+
+class PositionalLinear(nn.Module):
+    def __init__(self, in_features, out_features, seq_len=77, bias=True):
+        super().__init__()
+        self.linear = nn.Linear(in_features, out_features, bias=bias)
+        self.positional_embedding = nn.Parameter(torch.zeros(1, seq_len, out_features))
+        nn.init.trunc_normal_(self.positional_embedding, std=0.02)
+
+    def forward(self, x):
+        x = self.linear(x)
+        if x.dim() == 2:
+            x = x.unsqueeze(1) + self.positional_embedding
+        return x
+
+
+class LdmImplicitCaptionerExtractor(nn.Module):
+    """cond = uncond + tanh(alpha) * (Linear(prefix) + pos);  cond_emb = tanh(alpha_t) * (Linear_t(prefix) + pos_t)."""
+
+    def __init__(self, learnable_time_embed=True, num_timesteps=1, dim_latent=768, clip=None, **kwargs):
+        super().__init__()
+        assert clip is None
+        self.ldm_extractor = LdmExtractor(**kwargs)
+        self.clip_project = PositionalLinear(dim_latent, 768, 77)
+        self.alpha_cond = nn.Parameter(torch.zeros(1, 77, 768))
+        self.learnable_time_embed = learnable_time_embed
+        if learnable_time_embed:
+            self.time_embed_project = PositionalLinear(dim_latent, 1280, num_timesteps)
+            self.alpha_cond_time_embed = nn.Parameter(torch.zeros(1280))
+
+    feature_size = (512, 512)
+
+    @property
+    def feature_dims(self):
+        return self.ldm_extractor.feature_dims
+
+    @property
+    def feature_strides(self):
+        return self.ldm_extractor.feature_strides
+
+    @property
+    def grouped_indices(self):
+        return self.ldm_extractor.grouped_indices
+
+    def conditioning(self, prefix):
+        cond = self.ldm_extractor.ldm.uncond_inputs + torch.tanh(self.alpha_cond) * self.clip_project(prefix)
+        cond_emb = None
+        if self.learnable_time_embed:
+            cond_emb = torch.tanh(self.alpha_cond_time_embed) * self.time_embed_project(prefix)
+        return cond, cond_emb
+
+    def forward(self, batched_inputs, prefix):
+        cond, cond_emb = self.conditioning(prefix)
+        img = batched_inputs["img"]
+        return self.ldm_extractor(img, cond.to(img.dtype), cond_emb.to(img.dtype))
+
+
+# ----------------------------------------------------------------------------- projection backbone
+class _ConvGN(nn.Conv2d):
+    """detectron2 Conv2d(bias=False, norm=GroupNorm(32)) with optional ReLU; parameter names weight / norm.*"""
+
+    def __init__(self, cin, cout, k, padding=0, relu=False):
+        super().__init__(cin, cout, k, padding=padding, bias=False)
+        self.norm = nn.GroupNorm(32, cout)
+        self._relu = relu
+
+    def forward(self, x):
+        x = self.norm(super().forward(x))
+        return F.relu_(x) if self._relu else x
+
+
+class GNBottleneck(nn.Module):
+    def __init__(self, cin, bottleneck, cout):
+        super().__init__()
+        self.shortcut = _ConvGN(cin, cout, 1) if cin != cout else None
+        self.conv1 = _ConvGN(cin, bottleneck, 1, relu=True)
+        self.conv2 = _ConvGN(bottleneck, bottleneck, 3, padding=1, relu=True)
+        self.conv3 = _ConvGN(bottleneck, cout, 1)
+
+    def forward(self, x):
+        out = self.conv3(self.conv2(self.conv1(x)))
+        return F.relu_(out + (self.shortcut(x) if self.shortcut is not None else x))
+
+
+class FeatureExtractorBackbone(nn.Module):
+    def __init__(self, feature_extractor, out_features, backbone_in_size=(512, 512), min_stride=4, max_stride=32,
+                 projection_dim=512, num_res_blocks=1, use_checkpoint=False, slide_training=False):
+        super().__init__()
+        assert num_res_blocks == 1
+        self.feature_extractor = feature_extractor
+        self.use_checkpoint = use_checkpoint
+        self.feature_projections = nn.ModuleList(
+            nn.Sequential(GNBottleneck(d, projection_dim // 4, projection_dim)) for d in feature_extractor.feature_dims)
+        self.backbone_in_size = tuple(backbone_in_size)
+        stride_to_indices = defaultdict(list)
+        for indices in feature_extractor.grouped_indices:
+            for idx in indices:
+                s = min(max(feature_extractor.feature_strides[idx], min_stride), max_stride)
+                stride_to_indices[s].append(idx)
+        self._groups = []
+        self._out_feature_strides, self._out_feature_channels = {}, {}
+        for s in sorted(stride_to_indices):
+            name = f"s{int(math.log2(s))}"
+            if name in out_features:
+                self._groups.append((name, s, stride_to_indices[s]))
+                self._out_feature_strides[name], self._out_feature_channels[name] = s, projection_dim
+        self._out_features = [g[0] for g in self._groups]
+
+    size_divisibility = 64
+
+    def output_shape(self):
+        return {n: (self._out_feature_channels[n], self._out_feature_strides[n]) for n in self._out_features}
+
+    def forward_features(self, features, input_image_size):
+        out = {}
+        for name, stride, indices in self._groups:
+            acc = None
+            for idx in indices:
+                f = F.interpolate(features[idx], size=(input_image_size[-2] // stride, input_image_size[-1] // stride))
+                p = self.feature_projections[idx](f)
+                acc = p if acc is None else acc + p
+            out[name] = acc
+        return out
+
+    def forward(self, img, imp_condition):
+        """img (B,3,H,W) in [0,1] (H=W=512 in every XMask3D config -> one 1x1 sliding window, feature_extractor.py:169-226)."""
+        h, w = img.shape[-2:]
+        if (h, w) != self.backbone_in_size:
+            img = F.interpolate(img, size=self.backbone_in_size, mode="bicubic", align_corners=False)
+        feats = self.feature_extractor(dict(img=img), imp_condition)
+        if self.use_checkpoint and torch.is_grad_enabled():
+            from torch.utils.checkpoint import checkpoint
+
+            return checkpoint(self.forward_features, feats, (h, w), use_reentrant=False)
+        return self.forward_features(feats, (h, w))

@@ -1,0 +1,392 @@
+"""Mask2Former head of XMask3D: MSDeformAttn pixel decoder + masked transformer decoder with
+pooled mask-CLIP embedding.
+
+Same module / parameter names as the reference so checkpoints map 1:1:
+  * MSDeformAttnPixelDecoder   third_party/Mask2Former/mask2former/modeling/pixel_decoder/msdeformattn.py:23-358
+  * PositionEmbeddingSine      .../transformer_decoder/position_encoding.py:11-52   (pinned: tests/golden/sine_pe.npz)
+  * Self/Cross-attention, FFN, MLP, MultiScaleMaskedTransformerDecoder
+                               .../transformer_decoder/mask2former_transformer_decoder.py:17-204,225-365
+  * ODISEMultiScaleMaskedTransformerDecoder, PseudoClassEmbed, MaskPooling, PooledMaskEmbed
+                               /root/reference/models/modeling/meta_arch/odise.py:329-597
+  * MaskFormerHead glue        .../meta_arch/mask_former_head.py:115-132
+The deformable-attention sampling runs on the HIP kernels of xmask3d_amd.msda.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .msda import MSDeformAttn
+
+
+class PositionEmbeddingSine(nn.Module):
+    def __init__(self, num_pos_feats=64, temperature=10000, normalize=False, scale=None):
+        super().__init__()
+        if scale is not None and normalize is False:
+            raise ValueError("normalize should be True if scale is passed")
+        self.num_pos_feats, self.temperature, self.normalize = num_pos_feats, temperature, normalize
+        self.scale = 2 * math.pi if scale is None else scale
+
+    def forward(self, x, mask=None):
+        b, _, h, w = x.shape
+        dev = x.device
+        if mask is None:
+            y_embed = torch.arange(1, h + 1, dtype=torch.float32, device=dev).view(1, h, 1).expand(b, h, w)
+            x_embed = torch.arange(1, w + 1, dtype=torch.float32, device=dev).view(1, 1, w).expand(b, h, w)
+        else:
+            not_mask = ~mask
+            y_embed = not_mask.cumsum(1, dtype=torch.float32)
+            x_embed = not_mask.cumsum(2, dtype=torch.float32)
+        if self.normalize:
+            eps = 1e-6
+            y_embed = y_embed / (y_embed[:, -1:, :] + eps) * self.scale
+            x_embed = x_embed / (x_embed[:, :, -1:] + eps) * self.scale
+        dim_t = torch.arange(self.num_pos_feats, dtype=torch.float32, device=dev)
+        dim_t = self.temperature ** (2 * torch.div(dim_t, 2, rounding_mode="floor") / self.num_pos_feats)
+        pos_x = x_embed[:, :, :, None] / dim_t
+        pos_y = y_embed[:, :, :, None] / dim_t
+        pos_x = torch.stack((pos_x[:, :, :, 0::2].sin(), pos_x[:, :, :, 1::2].cos()), dim=4).flatten(3)
+        pos_y = torch.stack((pos_y[:, :, :, 0::2].sin(), pos_y[:, :, :, 1::2].cos()), dim=4).flatten(3)
+        return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
+
+
+# ----------------------------------------------------------------------------- pixel decoder
+class MSDeformAttnTransformerEncoderLayer(nn.Module):
+    def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, n_levels=4, n_heads=8, n_points=4):
+        super().__init__()
+        self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
+        self.dropout1 = nn.Dropout(dropout)
+        self.norm1 = nn.LayerNorm(d_model)
+        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.dropout2 = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.dropout3 = nn.Dropout(dropout)
+        self.norm2 = nn.LayerNorm(d_model)
+
+    def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
+        src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask)
+        src = self.norm1(src + self.dropout1(src2))
+        src2 = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+        return self.norm2(src + self.dropout3(src2))
+
+
+class MSDeformAttnTransformerEncoder(nn.Module):
+    def __init__(self, layer_fn, num_layers):
+        super().__init__()
+        self.layers = nn.ModuleList(layer_fn() for _ in range(num_layers))
+        self.num_layers = num_layers
+
+    @staticmethod
+    def get_reference_points(spatial_shapes, valid_ratios, device):
+        refs = []
+        for lvl, (H_, W_) in enumerate(spatial_shapes):
+            ref_y, ref_x = torch.meshgrid(torch.linspace(0.5, H_ - 0.5, H_, dtype=torch.float32, device=device),
+                                          torch.linspace(0.5, W_ - 0.5, W_, dtype=torch.float32, device=device), indexing="ij")
+            ref_y = ref_y.reshape(-1)[None] / (valid_ratios[:, None, lvl, 1] * H_)
+            ref_x = ref_x.reshape(-1)[None] / (valid_ratios[:, None, lvl, 0] * W_)
+            refs.append(torch.stack((ref_x, ref_y), -1))
+        reference_points = torch.cat(refs, 1)
+        return reference_points[:, :, None] * valid_ratios[:, None]
+
+    def forward(self, src, spatial_shapes_list, spatial_shapes, level_start_index, valid_ratios, pos):
+        ref = self.get_reference_points(spatial_shapes_list, valid_ratios, src.device)
+        out = src
+        for layer in self.layers:
+            out = layer(out, pos, ref, spatial_shapes, level_start_index, None)
+        return out
+
+
+class MSDeformAttnTransformerEncoderOnly(nn.Module):
+    def __init__(self, d_model=256, nhead=8, num_encoder_layers=6, dim_feedforward=1024, dropout=0.1,
+                 num_feature_levels=4, enc_n_points=4):
+        super().__init__()
+        self.d_model, self.nhead = d_model, nhead
+        self.encoder = MSDeformAttnTransformerEncoder(
+            lambda: MSDeformAttnTransformerEncoderLayer(d_model, dim_feedforward, dropout, num_feature_levels, nhead, enc_n_points),
+            num_encoder_layers)
+        self.level_embed = nn.Parameter(torch.Tensor(num_feature_levels, d_model))
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+        for m in self.modules():
+            if isinstance(m, MSDeformAttn):
+                m._reset_parameters()
+        nn.init.normal_(self.level_embed)
+
+    def forward(self, srcs, pos_embeds):
+        shapes = [(s.shape[2], s.shape[3]) for s in srcs]
+        src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
+        pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
+        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src.device)
+        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        valid_ratios = torch.ones(src.shape[0], len(srcs), 2, dtype=torch.float32, device=src.device)  # no padding on this path
+        memory = self.encoder(src, shapes, spatial_shapes, level_start_index, valid_ratios, pos)
+        return memory, shapes, level_start_index
+
+
+class _Conv(nn.Conv2d):
+    """detectron2 Conv2d wrapper: optional GroupNorm under ``.norm`` and ReLU."""
+
+    def __init__(self, cin, cout, k, padding=0, bias=True, gn=False, relu=False):
+        super().__init__(cin, cout, k, padding=padding, bias=bias)
+        if gn:
+            self.norm = nn.GroupNorm(32, cout)
+        self._gn, self._relu = gn, relu
+
+    def forward(self, x):
+        x = super().forward(x)
+        if self._gn:
+            x = self.norm(x)
+        return F.relu_(x) if self._relu else x
+
+
+def _c2_xavier_fill(m):
+    nn.init.kaiming_uniform_(m.weight, a=1)
+    if m.bias is not None:
+        nn.init.constant_(m.bias, 0)
+
+
+class MSDeformAttnPixelDecoder(nn.Module):
+    def __init__(self, input_shape, *, transformer_dropout, transformer_nheads, transformer_dim_feedforward,
+                 transformer_enc_layers, conv_dim, mask_dim, norm="GN", transformer_in_features, common_stride):
+        """input_shape: {name: (channels, stride)}"""
+        super().__init__()
+        items = sorted(input_shape.items(), key=lambda kv: kv[1][1])
+        self.in_features = [k for k, _ in items]
+        self.feature_channels = [v[0] for _, v in items]
+        titems = [(k, v) for k, v in items if k in transformer_in_features]
+        self.transformer_in_features = [k for k, _ in titems]
+        self.transformer_feature_strides = [v[1] for _, v in titems]
+        self.transformer_num_feature_levels = len(titems)
+        self.input_proj = nn.ModuleList(
+            nn.Sequential(nn.Conv2d(v[0], conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for _, v in titems[::-1])
+        for proj in self.input_proj:
+            nn.init.xavier_uniform_(proj[0].weight, gain=1)
+            nn.init.constant_(proj[0].bias, 0)
+        self.transformer = MSDeformAttnTransformerEncoderOnly(conv_dim, transformer_nheads, transformer_enc_layers,
+                                                              transformer_dim_feedforward, transformer_dropout,
+                                                              self.transformer_num_feature_levels)
+        self.pe_layer = PositionEmbeddingSine(conv_dim // 2, normalize=True)
+        self.mask_dim = mask_dim
+        self.mask_features = _Conv(conv_dim, mask_dim, 1)
+        _c2_xavier_fill(self.mask_features)
+        self.maskformer_num_feature_levels = 3
+        self.common_stride = common_stride
+        self.num_fpn_levels = int(np.log2(min(self.transformer_feature_strides)) - np.log2(common_stride))
+        lateral, output = [], []
+        gn = norm == "GN"
+        for idx, cin in enumerate(self.feature_channels[: self.num_fpn_levels]):
+            lat = _Conv(cin, conv_dim, 1, bias=not gn, gn=gn)
+            out = _Conv(conv_dim, conv_dim, 3, padding=1, bias=not gn, gn=gn, relu=True)
+            _c2_xavier_fill(lat)
+            _c2_xavier_fill(out)
+            self.add_module(f"adapter_{idx + 1}", lat)
+            self.add_module(f"layer_{idx + 1}", out)
+            lateral.append(lat)
+            output.append(out)
+        self.lateral_convs, self.output_convs = lateral[::-1], output[::-1]
+
+    def forward_features(self, features):
+        srcs, pos = [], []
+        for idx, f in enumerate(self.transformer_in_features[::-1]):
+            x = features[f].float()  # deformable attention is f32 in the reference too (msdeformattn.py:320)
+            srcs.append(self.input_proj[idx](x))
+            pos.append(self.pe_layer(x))
+        y, shapes, level_start_index = self.transformer(srcs, pos)
+        bs = y.shape[0]
+        sizes = [h * w for h, w in shapes]
+        out = [z.transpose(1, 2).reshape(bs, -1, h, w) for z, (h, w) in zip(torch.split(y, sizes, dim=1), shapes)]
+        for idx, f in enumerate(self.in_features[: self.num_fpn_levels][::-1]):
+            cur = self.lateral_convs[idx](features[f].float())
+            y = cur + F.interpolate(out[-1], size=cur.shape[-2:], mode="bilinear", align_corners=False)
+            out.append(self.output_convs[idx](y))
+        return self.mask_features(out[-1]), out[0], out[: self.maskformer_num_feature_levels]
+
+
+# ----------------------------------------------------------------------------- transformer decoder
+class SelfAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0):
+        super().__init__()
+        self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt, query_pos=None):
+        q = k = tgt + query_pos
+        return self.norm(tgt + self.self_attn(q, k, value=tgt, need_weights=False)[0])
+
+
+class CrossAttentionLayer(nn.Module):
+    def __init__(self, d_model, nhead, dropout=0.0):
+        super().__init__()
+        self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt, memory, memory_mask=None, pos=None, query_pos=None):
+        tgt2 = self.multihead_attn(query=tgt + query_pos, key=memory + pos, value=memory, attn_mask=memory_mask,
+                                   need_weights=False)[0]
+        return self.norm(tgt + tgt2)
+
+
+class FFNLayer(nn.Module):
+    def __init__(self, d_model, dim_feedforward=2048):
+        super().__init__()
+        self.linear1 = nn.Linear(d_model, dim_feedforward)
+        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.norm = nn.LayerNorm(d_model)
+        for p in self.parameters():
+            if p.dim() > 1:
+                nn.init.xavier_uniform_(p)
+
+    def forward(self, tgt):
+        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))))
+
+
+class MLP(nn.Module):
+    def __init__(self, input_dim, hidden_dim, output_dim, num_layers):
+        super().__init__()
+        self.num_layers = num_layers
+        h = [hidden_dim] * (num_layers - 1)
+        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+
+    def forward(self, x):
+        for i, layer in enumerate(self.layers):
+            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+        return x
+
+
+class PseudoClassEmbed(nn.Module):
+    def __init__(self, num_classes):
+        super().__init__()
+        self.num_classes = num_classes
+
+    def forward(self, x):
+        fg = torch.ones((*x.shape[:-1], self.num_classes), dtype=x.dtype, device=x.device)
+        bg = torch.zeros((*x.shape[:-1], 1), dtype=x.dtype, device=x.device)
+        return torch.cat([fg, bg], dim=-1)
+
+
+class MaskPooling(nn.Module):
+    def __init__(self, hard_pooling=True, mask_threshold=0.5):
+        super().__init__()
+        self.hard_pooling, self.mask_threshold = hard_pooling, mask_threshold
+
+    def forward(self, x, mask):
+        mask = mask.detach().sigmoid()
+        if self.hard_pooling:
+            mask = (mask > self.mask_threshold).to(mask.dtype)
+        denorm = mask.sum(dim=(-1, -2), keepdim=True) + 1e-8
+        return {"mask_pooled_features": torch.einsum("bchw,bqhw->bqc", x, mask / denorm)}
+
+
+class PooledMaskEmbed(nn.Module):
+    def __init__(self, hidden_dim, mask_dim, projection_dim, temperature=0.07):
+        super().__init__()
+        self.pool_proj = nn.Sequential(nn.LayerNorm(hidden_dim), nn.Linear(hidden_dim, hidden_dim))
+        self.mask_embed = nn.Sequential(nn.LayerNorm(mask_dim), MLP(mask_dim, hidden_dim, projection_dim, 3))
+        self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / temperature))
+        self.mask_pooling = MaskPooling()
+
+    def forward(self, decoder_output, input_mask_embed, mask_features, pred_logits, pred_masks):
+        pooled = self.mask_pooling(mask_features, pred_masks)["mask_pooled_features"]
+        pooled = self.pool_proj(pooled) + decoder_output
+        return {"mask_embed": self.mask_embed(pooled), "mask_pooled_features": pooled,
+                "logit_scale": torch.clamp(self.logit_scale.exp(), max=100)}
+
+
+class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
+    def __init__(self, *, in_channels, mask_classification=True, num_classes, hidden_dim, num_queries, nheads,
+                 dim_feedforward, dec_layers, pre_norm, mask_dim, enforce_input_project, class_embed=None,
+                 post_mask_embed=None):
+        super().__init__()
+        assert mask_classification and not pre_norm
+        self.mask_classification = True
+        self.pe_layer = PositionEmbeddingSine(hidden_dim // 2, normalize=True)
+        self.num_heads, self.num_layers = nheads, dec_layers
+        self.transformer_self_attention_layers = nn.ModuleList(SelfAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
+        self.transformer_cross_attention_layers = nn.ModuleList(CrossAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
+        self.transformer_ffn_layers = nn.ModuleList(FFNLayer(hidden_dim, dim_feedforward) for _ in range(dec_layers))
+        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.num_queries = num_queries
+        self.query_feat = nn.Embedding(num_queries, hidden_dim)
+        self.query_embed = nn.Embedding(num_queries, hidden_dim)
+        self.num_feature_levels = 3
+        self.level_embed = nn.Embedding(self.num_feature_levels, hidden_dim)
+        self.input_proj = nn.ModuleList()
+        for _ in range(self.num_feature_levels):
+            if in_channels != hidden_dim or enforce_input_project:
+                conv = nn.Conv2d(in_channels, hidden_dim, kernel_size=1)
+                _c2_xavier_fill(conv)
+                self.input_proj.append(conv)
+            else:
+                self.input_proj.append(nn.Sequential())
+        self.class_embed = class_embed if class_embed is not None else nn.Linear(hidden_dim, num_classes + 1)
+        self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
+        self.post_mask_embed = post_mask_embed
+
+    def forward(self, x, mask_features, mask=None):
+        assert len(x) == self.num_feature_levels
+        src, pos, size_list = [], [], []
+        for i in range(self.num_feature_levels):
+            size_list.append(x[i].shape[-2:])
+            pos.append(self.pe_layer(x[i], None).flatten(2).permute(2, 0, 1))
+            src.append((self.input_proj[i](x[i]).flatten(2) + self.level_embed.weight[i][None, :, None]).permute(2, 0, 1))
+        bs = src[0].shape[1]
+        query_embed = self.query_embed.weight.unsqueeze(1).repeat(1, bs, 1)
+        output = self.query_feat.weight.unsqueeze(1).repeat(1, bs, 1)
+        cls_l, mask_l, extra_l = [], [], []
+        c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[0])
+        cls_l.append(c), mask_l.append(m), extra_l.append(e)
+        for i in range(self.num_layers):
+            lvl = i % self.num_feature_levels
+            # a query whose mask is empty everywhere attends to everything (odise.py:395)
+            full = attn_mask.all(dim=-1, keepdim=True)
+            attn_mask = attn_mask & ~full
+            output = self.transformer_cross_attention_layers[i](output, src[lvl], memory_mask=attn_mask, pos=pos[lvl],
+                                                                query_pos=query_embed)
+            output = self.transformer_self_attention_layers[i](output, query_pos=query_embed)
+            output = self.transformer_ffn_layers[i](output)
+            c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[(i + 1) % self.num_feature_levels])
+            cls_l.append(c), mask_l.append(m), extra_l.append(e)
+        out = {"pred_logits": cls_l[-1], "pred_masks": mask_l[-1],
+               "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(cls_l[:-1], mask_l[:-1])]}
+        for k in extra_l[-1]:
+            out[k] = extra_l[-1][k]
+            for i in range(len(extra_l) - 1):
+                out["aux_outputs"][i][k] = extra_l[i][k]
+        return out
+
+    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size):
+        decoder_output = self.decoder_norm(output).transpose(0, 1)
+        outputs_class = self.class_embed(decoder_output)
+        mask_embed = self.mask_embed(decoder_output)
+        outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
+        extra = {}
+        if self.post_mask_embed is not None:
+            extra.update(self.post_mask_embed(decoder_output, mask_embed, mask_features, outputs_class, outputs_mask))
+        attn_mask = F.interpolate(outputs_mask, size=attn_mask_target_size, mode="bilinear", align_corners=False)
+        attn_mask = (attn_mask.sigmoid().flatten(2).unsqueeze(1).repeat(1, self.num_heads, 1, 1).flatten(0, 1) < 0.5).bool()
+        return outputs_class, outputs_mask, attn_mask.detach(), extra
+
+
+class MaskFormerHead(nn.Module):
+    def __init__(self, input_shape=None, *, num_classes, pixel_decoder, loss_weight=1.0, ignore_value=-1,
+                 transformer_predictor, transformer_in_feature):
+        super().__init__()
+        self.ignore_value, self.loss_weight = ignore_value, loss_weight
+        self.pixel_decoder, self.predictor = pixel_decoder, transformer_predictor
+        self.transformer_in_feature, self.num_classes = transformer_in_feature, num_classes
+        assert transformer_in_feature == "multi_scale_pixel_decoder"
+
+    def forward(self, features, mask=None):
+        mask_features, _, multi_scale_features = self.pixel_decoder.forward_features(features)
+        return self.predictor(multi_scale_features, mask_features, mask)

@@ -1,0 +1,146 @@
+"""Scene-level inference: per-view sample assembly, model forward, open-vocabulary ensembling, voting.
+
+The counterpart of the reference's driver loop ``validate`` (/root/reference/run/infer.py:338-911) and of
+the per-view assembly in ``ScannetLoaderFull.__getitem__`` (dataset/data_loader_infer.py:161-283), kept
+on the device: no ``.cpu()`` round trips, no sklearn KD-tree (nearest-neighbour fill is a chunked
+distance arg-min on the GPU), no per-mask Python loop (final masks are pixel-disjoint, so the sequential
+update of run/infer.py:585-601 equals one gather).  Results follow the reference formulae:
+  logits      = logit_scale * norm(f) @ norm(text).T                          (infer.py:556-558)
+  ensembling  = p^r * p_open^(1-r) in log space, r = base_ratio / novel_ratio (infer.py:585-601)
+  gating      = binary_pred ? base columns : novel columns                    (infer.py:603-612)
+  vote        = scene_pred[visible, cls] += 1 ; unseen points <- nearest seen (infer.py:642-694)
+"""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from . import me_compat as ME
+from . import synthetic
+from .voxelizer import Voxelizer
+
+ROT_BOUND = ((-np.pi / 64, np.pi / 64), (-np.pi / 64, np.pi / 64), (-np.pi, np.pi))
+
+
+def default_voxelizer(voxel_size=0.02, device="cuda"):
+    """dataset/point_loader.py:52-60,100-107"""
+    return Voxelizer(voxel_size=voxel_size, clip_bound=None, use_augmentation=True, scale_augmentation_bound=(0.9, 1.1),
+                     rotation_augmentation_bound=ROT_BOUND,
+                     translation_augmentation_ratio_bound=((-0.2, 0.2), (-0.2, 0.2), (0, 0)), device=device)
+
+
+class SceneOnDevice:
+    """A scene uploaded once: points (f64), colours, per-view visibility / pixel labels / images."""
+
+    def __init__(self, scene: synthetic.Scene, device):
+        self.device = device
+        self.points = torch.from_numpy(scene.points).to(device)
+        self.colors = torch.from_numpy(scene.colors).to(device)
+        self.n = scene.points.shape[0]
+        self.views = []
+        for v in range(len(scene.poses)):
+            vis, rows, cols = synthetic.view_subset(scene, v)
+            self.views.append(dict(
+                vis=torch.from_numpy(vis).to(device),
+                idx=torch.from_numpy(np.nonzero(vis)[0]).to(device),
+                x=torch.from_numpy(rows).long().to(device), y=torch.from_numpy(cols).long().to(device),
+                img=torch.from_numpy(scene.images[v]).permute(2, 0, 1)[None].contiguous().to(device),
+                caption=scene.captions[v]))
+
+
+def build_view_batch(sd: SceneOnDevice, view: int, voxelizer: Voxelizer, matrix=None):
+    """-> batch_input dict of XMASK3d.forward for one view (batch 1), everything on the device."""
+    v = sd.views[view]
+    pts = sd.points[v["idx"]].contiguous()
+    grid, inds, inverse = voxelizer.voxelize_device(pts, matrix)
+    coords = torch.cat([torch.zeros(grid.shape[0], 1, dtype=torch.int32, device=sd.device), grid], 1).contiguous()
+    feats = (sd.colors[v["idx"]][inds] / 127.5 - 1.0).float().contiguous()
+    ori = torch.cat([torch.zeros(pts.shape[0], 1, device=sd.device), pts.float()], 1)
+    return {"sinput": ME.SparseTensor(feats, coords), "img": v["img"], "x_label": v["x"], "y_label": v["y"],
+            "inds_reconstruct": inverse, "ori_coords": ori, "captions": (v["caption"],), "coords": coords,
+            "label_2d": None, "labels_3d": None, "use_pure_3d": False}
+
+
+def nearest_index(query: torch.Tensor, ref: torch.Tensor, chunk=8192):
+    """index into ref of the nearest reference point for every query point (exact, chunked)."""
+    out = torch.empty(query.shape[0], dtype=torch.long, device=query.device)
+    r2 = (ref * ref).sum(1)[None]
+    for s in range(0, query.shape[0], chunk):
+        q = query[s:s + chunk]
+        d = (q * q).sum(1)[:, None] + r2 - 2.0 * (q @ ref.T)
+        out[s:s + chunk] = d.argmin(1)
+    return out
+
+
+def _gate(logits, binary_pred, base, novel):
+    lb, ln = logits.clone(), logits.clone()
+    ln[:, base] = -1e10
+    lb[:, novel] = -1e10
+    return binary_pred * lb + (1 - binary_pred) * ln
+
+
+def postprocess_view(cfg, outputs, batch, with_ablations=True):
+    """-> class id per visible point for the fused / 2D-only / 3D-only predictions."""
+    cs = cfg.category_split
+    base, novel, allc = list(cs["base_category"]), list(cs["novel_category"]), list(cs["all_category"])
+    text = F.normalize(outputs["text_embed"], dim=-1)
+    scale = outputs["logit_scale"]
+    binary_pred = outputs["binary_pred"]
+    fused = F.normalize(torch.cat(outputs["fused_pred_feature"]), dim=-1)
+    probs = (scale * (fused @ text.t())).softmax(dim=-1)
+    open_emb = torch.cat(outputs["final_pred_open_embedding"])
+    masks = torch.cat(outputs["final_mask_3d"])
+    if masks.shape[0] > 0:
+        open_p = (scale * (F.normalize(open_emb, dim=-1) @ text.t())).softmax(dim=-1)
+        overlap = torch.tensor([int(c in base) for c in allc], device=probs.device, dtype=probs.dtype)
+        covered = masks.any(0)
+        q = masks.float().argmax(0)  # masks are pixel-disjoint: at most one per point
+        po = open_p[q]
+        b = (probs ** cfg.base_ratio * po ** (1 - cfg.base_ratio)).log() * overlap
+        n = (probs ** cfg.novel_ratio * po ** (1 - cfg.novel_ratio)).log() * (1 - overlap)
+        probs = torch.where(covered[:, None], b + n, probs)
+    pred = _gate(probs, binary_pred, base, novel).argmax(1)
+    if not with_ablations:
+        return pred, None, None
+    f2d = torch.cat(outputs["2d_pred_feature"]).clone()
+    empty = f2d.sum(1) == 0
+    if bool(empty.any()) and not bool(empty.all()):
+        xyz = batch["ori_coords"][:, 1:]
+        src = torch.nonzero(~empty)[:, 0]
+        f2d[empty] = f2d[src[nearest_index(xyz[empty], xyz[src])]]
+    pred2d = _gate(scale * (F.normalize(f2d, dim=-1) @ text.t()), binary_pred, base, novel).argmax(1)
+    f3d = F.normalize(torch.cat(outputs["pure3d_pred_feature"]), dim=-1)
+    pred3d = _gate(scale * (f3d @ text.t()), binary_pred, base, novel).argmax(1)
+    return pred, pred2d, pred3d
+
+
+@torch.no_grad()
+def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, with_ablations=True):
+    """Loop over the views of one scene (batch 1 each, like the reference), vote, fill unseen points.
+    matrices: optional list of 4x4 voxelisation transforms (otherwise drawn from np.random like the reference)."""
+    voxelizer = voxelizer or default_voxelizer(cfg.voxel_size, sd.device)
+    ncls = len(cfg.category_split["base_category"]) + len(cfg.category_split["novel_category"])
+    votes = [torch.zeros((sd.n, ncls), dtype=torch.int32, device=sd.device) for _ in range(3 if with_ablations else 1)]
+    seen = torch.zeros(sd.n, dtype=torch.bool, device=sd.device)
+    for v in range(len(sd.views)):
+        batch = build_view_batch(sd, v, voxelizer, None if matrices is None else matrices[v])
+        _, outputs = model(batch)
+        preds = postprocess_view(cfg, outputs, batch, with_ablations)
+        idx = sd.views[v]["idx"]
+        for vt, p in zip(votes, preds):
+            if p is not None:
+                vt.index_put_((idx, p), torch.ones_like(p, dtype=torch.int32), accumulate=True)
+        seen[idx] = True
+    out = []
+    fill = None
+    if not bool(seen.all()) and bool(seen.any()):
+        src = torch.nonzero(seen)[:, 0]
+        xyz = sd.points.float()
+        fill = src[nearest_index(xyz[~seen], xyz[src])]
+    for vt in votes:
+        p = vt.argmax(1)
+        if fill is not None:
+            p[~seen] = p[fill]
+        out.append(p)
+    return out

@@ -1,0 +1,378 @@
+"""Stable-Diffusion v1 autoencoder (KL-f8) and denoising UNet, restated in plain torch.
+
+The reference reaches these through the un-vendored dependency
+``stable-diffusion-sdkit==2.1.3`` (``ldm.*``; /root/reference/setup.py:33,
+call sites /root/reference/models/modeling/meta_arch/ldm.py:7-10,386-490).  That
+package is absent here, so the published SD-v1 architecture
+(``v1-inference.yaml``: VAE ch=128, ch_mult (1,2,4,4), 2 res blocks, z=4; UNet
+model_channels=320, channel_mult (1,2,4,4), 2 res blocks, attention at ds 1/2/4,
+8 heads, context_dim 768) is written out again.  Module / parameter names follow
+the ldm state-dict layout (``encoder.down.0.block.0.norm1.weight``,
+``input_blocks.1.1.transformer_blocks.0.attn1.to_q.weight`` ...) so that
+``sd-v1-3.ckpt`` can be mapped onto it once it is available.
+PARITY UNPINNED for the numerics of this file: nothing in /root/reference pins
+them; tests check structure (tap shapes/strides) and GPU-vs-CPU agreement of the
+same modules.
+
+Only what the feature extractor executes is built: the encoder, the UNet, the
+decoder; `taps` arguments name the blocks whose INPUT is returned as a feature.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+
+def swish(x):
+    return x * torch.sigmoid(x)
+
+
+def group_norm(c, eps):
+    return nn.GroupNorm(32, c, eps=eps, affine=True)
+
+
+# ----------------------------------------------------------------------------- VAE
+class VaeResBlock(nn.Module):
+    def __init__(self, cin, cout):
+        super().__init__()
+        self.in_channels, self.out_channels = cin, cout
+        self.norm1 = group_norm(cin, 1e-6)
+        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.norm2 = group_norm(cout, 1e-6)
+        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        if cin != cout:
+            self.nin_shortcut = nn.Conv2d(cin, cout, 1)
+
+    def forward(self, x, temb=None):
+        h = self.conv1(swish(self.norm1(x)))
+        h = self.conv2(swish(self.norm2(h)))
+        if self.in_channels != self.out_channels:
+            x = self.nin_shortcut(x)
+        return x + h
+
+
+class VaeAttnBlock(nn.Module):
+    """single-head attention over all H*W positions"""
+
+    def __init__(self, c):
+        super().__init__()
+        self.norm = group_norm(c, 1e-6)
+        self.q = nn.Conv2d(c, c, 1)
+        self.k = nn.Conv2d(c, c, 1)
+        self.v = nn.Conv2d(c, c, 1)
+        self.proj_out = nn.Conv2d(c, c, 1)
+
+    def forward(self, x):
+        h = self.norm(x)
+        b, c, hh, ww = h.shape
+        q = self.q(h).reshape(b, 1, c, hh * ww).transpose(2, 3)
+        k = self.k(h).reshape(b, 1, c, hh * ww).transpose(2, 3)
+        v = self.v(h).reshape(b, 1, c, hh * ww).transpose(2, 3)
+        o = F.scaled_dot_product_attention(q, k, v)  # scale = c^-0.5
+        o = o.transpose(2, 3).reshape(b, c, hh, ww)
+        return x + self.proj_out(o)
+
+
+class VaeDownsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
+
+    def forward(self, x):
+        return self.conv(F.pad(x, (0, 1, 0, 1)))
+
+
+class VaeUpsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class _Level(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.block = nn.ModuleList()
+        self.attn = nn.ModuleList()
+
+
+class _Mid(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.block_1 = VaeResBlock(c, c)
+        self.attn_1 = VaeAttnBlock(c)
+        self.block_2 = VaeResBlock(c, c)
+
+    def forward(self, h):
+        return self.block_2(self.attn_1(self.block_1(h)))
+
+
+class VaeEncoder(nn.Module):
+    def __init__(self, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, z_channels=4):
+        super().__init__()
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        self.conv_in = nn.Conv2d(in_channels, ch, 3, padding=1)
+        self.down = nn.ModuleList()
+        cin = ch
+        for i, m in enumerate(ch_mult):
+            lvl = _Level()
+            for _ in range(num_res_blocks):
+                lvl.block.append(VaeResBlock(cin, ch * m))
+                cin = ch * m
+            if i != len(ch_mult) - 1:
+                lvl.downsample = VaeDownsample(cin)
+            self.down.append(lvl)
+        self.mid = _Mid(cin)
+        self.norm_out = group_norm(cin, 1e-6)
+        self.conv_out = nn.Conv2d(cin, 2 * z_channels, 3, padding=1)
+
+    def forward(self, x, taps=()):
+        """taps: flat block indices (level*num_res_blocks + block) whose input is recorded."""
+        feats = []
+        h = self.conv_in(x)
+        for i, lvl in enumerate(self.down):
+            for j, blk in enumerate(lvl.block):
+                if i * self.num_res_blocks + j in taps:
+                    feats.append(h.contiguous())
+                h = blk(h)
+            if i != self.num_resolutions - 1:
+                h = lvl.downsample(h)
+        h = self.mid(h)
+        return self.conv_out(swish(self.norm_out(h))), feats
+
+
+class VaeDecoder(nn.Module):
+    def __init__(self, ch=128, out_ch=3, ch_mult=(1, 2, 4, 4), num_res_blocks=2, z_channels=4):
+        super().__init__()
+        self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
+        cin = ch * ch_mult[-1]
+        self.conv_in = nn.Conv2d(z_channels, cin, 3, padding=1)
+        self.mid = _Mid(cin)
+        self.up = nn.ModuleList([_Level() for _ in ch_mult])
+        for i in reversed(range(len(ch_mult))):
+            for _ in range(num_res_blocks + 1):
+                self.up[i].block.append(VaeResBlock(cin, ch * ch_mult[i]))
+                cin = ch * ch_mult[i]
+            if i != 0:
+                self.up[i].upsample = VaeUpsample(cin)
+        self.norm_out = group_norm(cin, 1e-6)
+        self.conv_out = nn.Conv2d(cin, out_ch, 3, padding=1)
+
+    def forward(self, z, taps=(), stop_after_taps=False):
+        """taps: flat indices over (level descending, block ascending).  With stop_after_taps the decoder
+        returns as soon as the last tap has been recorded (the image itself is never used by XMask3D)."""
+        feats = []
+        h = self.mid(self.conv_in(z))
+        idx = 0
+        last = max(taps) if taps else -1
+        for i in reversed(range(self.num_resolutions)):
+            for blk in self.up[i].block:
+                if idx in taps:
+                    feats.append(h.contiguous())
+                    if stop_after_taps and idx == last:
+                        return None, feats
+                h = blk(h)
+                idx += 1
+            if i != 0:
+                h = self.up[i].upsample(h)
+        return self.conv_out(swish(self.norm_out(h))), feats
+
+
+class AutoencoderKL(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.encoder = VaeEncoder()
+        self.decoder = VaeDecoder()
+        self.quant_conv = nn.Conv2d(8, 8, 1)
+        self.post_quant_conv = nn.Conv2d(4, 4, 1)
+
+
+# ----------------------------------------------------------------------------- UNet
+def timestep_embedding(t, dim, max_period=10000):
+    half = dim // 2
+    freqs = torch.exp(-math.log(max_period) * torch.arange(half, dtype=torch.float32, device=t.device) / half)
+    args = t[:, None].float() * freqs[None]
+    return torch.cat([torch.cos(args), torch.sin(args)], dim=-1)
+
+
+class UNetResBlock(nn.Module):
+    def __init__(self, cin, emb_ch, cout):
+        super().__init__()
+        self.channels, self.out_channels = cin, cout
+        self.in_layers = nn.Sequential(group_norm(cin, 1e-5), nn.SiLU(), nn.Conv2d(cin, cout, 3, padding=1))
+        self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_ch, cout))
+        self.out_layers = nn.Sequential(group_norm(cout, 1e-5), nn.SiLU(), nn.Dropout(0.0), nn.Conv2d(cout, cout, 3, padding=1))
+        self.skip_connection = nn.Identity() if cin == cout else nn.Conv2d(cin, cout, 1)
+
+    def forward(self, x, emb):
+        h = self.in_layers(x)
+        h = h + self.emb_layers(emb).to(h.dtype)[:, :, None, None]
+        return self.skip_connection(x) + self.out_layers(h)
+
+
+class CrossAttention(nn.Module):
+    def __init__(self, query_dim, context_dim=None, heads=8, dim_head=64):
+        super().__init__()
+        inner = heads * dim_head
+        context_dim = context_dim or query_dim
+        self.heads = heads
+        self.to_q = nn.Linear(query_dim, inner, bias=False)
+        self.to_k = nn.Linear(context_dim, inner, bias=False)
+        self.to_v = nn.Linear(context_dim, inner, bias=False)
+        self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(0.0))
+
+    def forward(self, x, context=None):
+        context = x if context is None else context
+        b, n, _ = x.shape
+        h = self.heads
+        q = self.to_q(x).view(b, n, h, -1).transpose(1, 2)
+        k = self.to_k(context).view(b, context.shape[1], h, -1).transpose(1, 2)
+        v = self.to_v(context).view(b, context.shape[1], h, -1).transpose(1, 2)
+        o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, n, -1)
+        return self.to_out(o)
+
+
+class GEGLU(nn.Module):
+    def __init__(self, dim_in, dim_out):
+        super().__init__()
+        self.proj = nn.Linear(dim_in, dim_out * 2)
+
+    def forward(self, x):
+        x, gate = self.proj(x).chunk(2, dim=-1)
+        return x * F.gelu(gate)
+
+
+class FeedForward(nn.Module):
+    def __init__(self, dim, mult=4):
+        super().__init__()
+        self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim))
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class BasicTransformerBlock(nn.Module):
+    def __init__(self, dim, heads, dim_head, context_dim):
+        super().__init__()
+        self.attn1 = CrossAttention(dim, None, heads, dim_head)
+        self.ff = FeedForward(dim)
+        self.attn2 = CrossAttention(dim, context_dim, heads, dim_head)
+        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+
+    def forward(self, x, context):
+        x = self.attn1(self.norm1(x)) + x
+        x = self.attn2(self.norm2(x), context) + x
+        return self.ff(self.norm3(x)) + x
+
+
+class SpatialTransformer(nn.Module):
+    def __init__(self, c, heads, dim_head, context_dim=768):
+        super().__init__()
+        self.norm = group_norm(c, 1e-6)
+        self.proj_in = nn.Conv2d(c, heads * dim_head, 1)
+        self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(heads * dim_head, heads, dim_head, context_dim)])
+        self.proj_out = nn.Conv2d(heads * dim_head, c, 1)
+
+    def forward(self, x, context):
+        b, c, h, w = x.shape
+        y = self.proj_in(self.norm(x)).flatten(2).transpose(1, 2)
+        for blk in self.transformer_blocks:
+            y = blk(y, context.to(y.dtype))
+        y = y.transpose(1, 2).reshape(b, -1, h, w)
+        return x + self.proj_out(y)
+
+
+class UNetDownsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.op = nn.Conv2d(c, c, 3, stride=2, padding=1)
+
+    def forward(self, x):
+        return self.op(x)
+
+
+class UNetUpsample(nn.Module):
+    def __init__(self, c):
+        super().__init__()
+        self.conv = nn.Conv2d(c, c, 3, padding=1)
+
+    def forward(self, x):
+        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+
+
+class TimestepSeq(nn.Sequential):
+    def forward(self, x, emb, context):
+        for layer in self:
+            if isinstance(layer, UNetResBlock):
+                x = layer(x, emb)
+            elif isinstance(layer, SpatialTransformer):
+                x = layer(x, context)
+            else:
+                x = layer(x)
+        return x
+
+
+class UNetModel(nn.Module):
+    def __init__(self, in_channels=4, model_channels=320, out_channels=4, num_res_blocks=2, attention_resolutions=(4, 2, 1),
+                 channel_mult=(1, 2, 4, 4), num_heads=8, context_dim=768):
+        super().__init__()
+        self.model_channels = model_channels
+        emb = model_channels * 4
+        self.time_embed = nn.Sequential(nn.Linear(model_channels, emb), nn.SiLU(), nn.Linear(emb, emb))
+        self.input_blocks = nn.ModuleList([TimestepSeq(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
+        chans = [model_channels]
+        ch, ds = model_channels, 1
+        for level, mult in enumerate(channel_mult):
+            for _ in range(num_res_blocks):
+                layers = [UNetResBlock(ch, emb, mult * model_channels)]
+                ch = mult * model_channels
+                if ds in attention_resolutions:
+                    layers.append(SpatialTransformer(ch, num_heads, ch // num_heads, context_dim))
+                self.input_blocks.append(TimestepSeq(*layers))
+                chans.append(ch)
+            if level != len(channel_mult) - 1:
+                self.input_blocks.append(TimestepSeq(UNetDownsample(ch)))
+                chans.append(ch)
+                ds *= 2
+        self.middle_block = TimestepSeq(UNetResBlock(ch, emb, ch), SpatialTransformer(ch, num_heads, ch // num_heads, context_dim),
+                                        UNetResBlock(ch, emb, ch))
+        self.output_blocks = nn.ModuleList()
+        for level, mult in list(enumerate(channel_mult))[::-1]:
+            for i in range(num_res_blocks + 1):
+                ich = chans.pop()
+                layers = [UNetResBlock(ch + ich, emb, model_channels * mult)]
+                ch = model_channels * mult
+                if ds in attention_resolutions:
+                    layers.append(SpatialTransformer(ch, num_heads, ch // num_heads, context_dim))
+                if level and i == num_res_blocks:
+                    layers.append(UNetUpsample(ch))
+                    ds //= 2
+                self.output_blocks.append(TimestepSeq(*layers))
+        self.out = nn.Sequential(group_norm(ch, 1e-5), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
+
+    def forward(self, x, timesteps, context, cond_emb=None, taps=(), stop_after_taps=False):
+        """taps: indices of output_blocks whose (concatenated) input is recorded."""
+        feats = []
+        emb = self.time_embed(timestep_embedding(timesteps, self.model_channels).to(x.dtype))
+        if cond_emb is not None:
+            emb = emb + cond_emb.to(emb.dtype)
+        hs = []
+        h = x
+        for m in self.input_blocks:
+            h = m(h, emb, context)
+            hs.append(h)
+        h = self.middle_block(h, emb, context)
+        last = max(taps) if taps else -1
+        for i, m in enumerate(self.output_blocks):
+            h = torch.cat([h, hs.pop()], dim=1)
+            if i in taps:
+                feats.append(h.contiguous())
+                if stop_after_taps and i == last:
+                    return None, feats
+            h = m(h, emb, context)
+        return self.out(h), feats
