@@ -1,0 +1,18 @@
+"""Steady-state kernel stats from a rocprofv3 kernel trace: only dispatches after the last MIOpen naive/find kernel
+(or after --skip-frac of the span).  python tools/ktrace_window.py <dir> [n]"""
+import collections, csv, glob, re, sys
+d = sys.argv[1]; n = int(sys.argv[2]) if len(sys.argv) > 2 else 30
+f = sorted(glob.glob(d + "/**/*kernel_trace.csv", recursive=True))[-1]
+rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), r["Kernel_Name"]) for r in csv.DictReader(open(f))]
+rows.sort()
+cut = max([e for s, e, k in rows if "naive_conv" in k] + [rows[0][0]])
+rows = [r for r in rows if r[0] >= cut]
+span = (rows[-1][1] - rows[0][0]) / 1e6
+agg = collections.defaultdict(lambda: [0, 0])
+for s, e, k in rows:
+    k = re.sub(r"\(.*", "", k)[:90]
+    agg[k][0] += 1; agg[k][1] += e - s
+tot = sum(v[1] for v in agg.values()) / 1e6
+print(f"{f}: window {span:.1f} ms, kernels {len(rows)}, busy {tot:.1f} ms ({100*tot/span:.0f}%)")
+for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:n]:
+    print("  %-90s calls %6d avg %8.1f us total %8.2f ms %5.1f%%" % (k, c, t / c / 1e3, t / 1e6, 100 * t / 1e6 / tot))

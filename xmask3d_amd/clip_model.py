@@ -186,7 +186,8 @@ class MaskCLIP(ClipAdapter):
 
     def encode_image_with_mask(self, image, mask):
         v = self.clip.visual
-        image = self.clip_preprocess(image)
+        image = self.clip_preprocess(image.float())
+        mask = mask.float()
         b, q = mask.shape[:2]
         patch = v.conv1.kernel_size
         blocked = (F.max_pool2d(mask.sigmoid(), kernel_size=patch, stride=v.conv1.stride) < 0.5).reshape(b, q, -1)

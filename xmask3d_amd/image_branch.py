@@ -249,9 +249,13 @@ class FeatureExtractorBackbone(nn.Module):
         h, w = img.shape[-2:]
         if (h, w) != self.backbone_in_size:
             img = F.interpolate(img, size=self.backbone_in_size, mode="bicubic", align_corners=False)
+        # the frozen extractor runs natively in img.dtype (bf16 weights: no autocast casts, GroupNorm stays bf16 I/O);
+        # the trainable fp32 projections run under autocast when the features are bf16
         feats = self.feature_extractor(dict(img=img), imp_condition)
-        if self.use_checkpoint and torch.is_grad_enabled():
-            from torch.utils.checkpoint import checkpoint
+        low = img.dtype != torch.float32
+        with torch.autocast(device_type=img.device.type, dtype=img.dtype if low else torch.bfloat16, enabled=low):
+            if self.use_checkpoint and torch.is_grad_enabled():
+                from torch.utils.checkpoint import checkpoint
 
-            return checkpoint(self.forward_features, feats, (h, w), use_reentrant=False)
-        return self.forward_features(feats, (h, w))
+                return checkpoint(self.forward_features, feats, (h, w), use_reentrant=False)
+            return self.forward_features(feats, (h, w))

@@ -117,12 +117,20 @@ class MSDeformAttnTransformerEncoderOnly(nn.Module):
                 m._reset_parameters()
         nn.init.normal_(self.level_embed)
 
+    def _shape_tensors(self, shapes, device):
+        """(spatial_shapes, level_start_index) device constants, cached so graph capture sees no H2D copy"""
+        key = (tuple(shapes), str(device))
+        cache = self.__dict__.setdefault("_shape_cache", {})
+        if key not in cache:
+            ss = torch.as_tensor(shapes, dtype=torch.long, device=device)
+            cache[key] = (ss, torch.cat((ss.new_zeros((1,)), ss.prod(1).cumsum(0)[:-1])))
+        return cache[key]
+
     def forward(self, srcs, pos_embeds):
         shapes = [(s.shape[2], s.shape[3]) for s in srcs]
         src = torch.cat([s.flatten(2).transpose(1, 2) for s in srcs], 1)
         pos = torch.cat([p.flatten(2).transpose(1, 2) + self.level_embed[l].view(1, 1, -1) for l, p in enumerate(pos_embeds)], 1)
-        spatial_shapes = torch.as_tensor(shapes, dtype=torch.long, device=src.device)
-        level_start_index = torch.cat((spatial_shapes.new_zeros((1,)), spatial_shapes.prod(1).cumsum(0)[:-1]))
+        spatial_shapes, level_start_index = self._shape_tensors(shapes, src.device)
         valid_ratios = torch.ones(src.shape[0], len(srcs), 2, dtype=torch.float32, device=src.device)  # no padding on this path
         memory = self.encoder(src, shapes, spatial_shapes, level_start_index, valid_ratios, pos)
         return memory, shapes, level_start_index

@@ -89,6 +89,10 @@ class XMASK3d(nn.Module):
         self.seq_len, self.size_divisibility = 77, 64
         self.dense_dtype = dense_dtype
         self.prune_dead_compute = prune_dead_compute
+        self.channels_last = False
+        self.register_buffer("_pixel_mean", torch.tensor(cfg.pixel_mean, dtype=torch.float32).view(1, 3, 1, 1), False)
+        self.register_buffer("_pixel_std", torch.tensor(cfg.pixel_std, dtype=torch.float32).view(1, 3, 1, 1), False)
+        self._dense_graphs = None
         self.pc_decoder = PC_Processor(arch_3d=cfg.arch_3d)
         self.pc_binary_head = PC_Binary_Processor(arch_3d=cfg.arch_binary_head)
         cs = cfg.category_split
@@ -137,9 +141,14 @@ class XMASK3d(nn.Module):
         null_pred = logit_scale * (mask_embed @ F.normalize(outputs["null_embed"], dim=-1).t())
         return torch.cat([pred, null_pred], dim=-1)
 
-    def _autocast(self, device):
-        enabled = self.dense_dtype != torch.float32
-        return torch.autocast(device_type=device.type, dtype=self.dense_dtype if enabled else torch.bfloat16, enabled=enabled)
+    def set_channels_last(self, on=True):
+        """NHWC activations/weights for the frozen conv nets (MIOpen's bf16 implicit-GEMM kernels are NHWC)"""
+        self.channels_last = on
+        fmt = torch.channels_last if on else torch.contiguous_format
+        ldm = self.backbone.feature_extractor.ldm_extractor.ldm
+        for mod in (ldm.first_stage_model, ldm.unet_model, self.backbone.feature_projections):
+            mod.to(memory_format=fmt)
+        return self
 
     def encode_3d(self, sinput, inds_reconstruct, batch_size):
         imp_condition, pred_3d, idx = self.pc_decoder(sinput)
@@ -153,18 +162,55 @@ class XMASK3d(nn.Module):
         """img (B,3,H,W) 0..255 -> decoder outputs + mask-CLIP embeddings."""
         dev = imp_condition_input.device
         img = img.to(dev).float()
-        mean = torch.tensor(self.pixel_mean, device=dev).view(1, 3, 1, 1)
-        std = torch.tensor(self.pixel_std, device=dev).view(1, 3, 1, 1)
-        images = (img - mean) / std
+        images = (img - self._pixel_mean) / self._pixel_std
         h, w = images.shape[-2:]
         ph, pw = (-h) % self.size_divisibility, (-w) % self.size_divisibility
         if ph or pw:
             images = F.pad(images, (0, pw, 0, ph))
-        with self._autocast(dev):
-            feature = self.backbone(images.to(self.dense_dtype), imp_condition_input)
+        images = images.to(self.dense_dtype)
+        if self.channels_last:
+            images = images.contiguous(memory_format=torch.channels_last)
+        feature = self.backbone(images, imp_condition_input)
         outputs = self.sem_seg_head({k: v.float() for k, v in feature.items()})
         outputs["images"] = img / 255.0
         return outputs
+
+    def dense_forward(self, img, cond):
+        """The static-shape part of the eval forward (rows a8-a17): SD feature extractor, projections, pixel +
+        transformer decoder, category logits, mask-CLIP.  img (B,3,H,W) 0..255 on device, cond (B,768)."""
+        outputs = self.encode_2d(img, cond)
+        outputs.update(self.category_head(outputs))
+        outputs["pred_logits"] = self.cal_pred_logits(outputs)
+        clip_embed = self.clip_head(outputs["images"], outputs["pred_masks"])  # casts to the visual tower's dtype inside
+        outputs["mask_embed_clip"] = clip_embed["mask_embed_clip"].float()
+        return outputs
+
+    def enable_dense_graph(self, on=True):
+        """Replay the static-shape dense branch as one HIP graph per input shape (inference only): ~2000 launch-bound
+        kernels per view stop paying host launch cost.  Outputs are static buffers, valid until the next call."""
+        self._dense_graphs = {} if on else None
+        return self
+
+    def _dense_graphed(self, img, cond):
+        key = (tuple(img.shape), img.dtype, self.dense_dtype, self.channels_last)
+        entry = self._dense_graphs.get(key)
+        if entry is None:
+            s_img, s_cond = img.clone(), cond.clone()
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm-up outside capture: MIOpen/hipBLASLt algorithm selection, constant caches
+                    self.dense_forward(s_img, s_cond)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                s_out = self.dense_forward(s_img, s_cond)
+            entry = self._dense_graphs[key] = (graph, s_img, s_cond, s_out)
+        graph, s_img, s_cond, s_out = entry
+        s_img.copy_(img)
+        s_cond.copy_(cond)
+        graph.replay()
+        return dict(s_out)
 
     # ------------------------------------------------------------------ forward
     def forward(self, batch_input):
@@ -179,15 +225,14 @@ class XMASK3d(nn.Module):
         pred_3d, cond, binary_scores = self.encode_3d(sinput, inds, B)
         if not self.prune_dead_compute:  # the reference embeds the captions in eval and never uses the result
             self.category_head.clip.embed_text(batch_input["captions"])
-        outputs = self.encode_2d(img, cond)
+        img = img.to(dev)
+        if self._dense_graphs is not None and not torch.is_grad_enabled():
+            outputs = self._dense_graphed(img, cond)
+        else:
+            outputs = self.dense_forward(img, cond)
         outputs["pred_3d"] = pred_3d
         binary_pred = (torch.sigmoid(binary_scores) > 0.5).long()
-        outputs.update(self.category_head(outputs))
-        outputs["pred_logits"] = self.cal_pred_logits(outputs)
         mask_cls_results = outputs["pred_logits"]
-        with self._autocast(dev):
-            clip_embed = self.clip_head(outputs["images"].to(self.dense_dtype), outputs["pred_masks"].to(self.dense_dtype))
-        outputs["mask_embed_clip"] = clip_embed["mask_embed_clip"].float()
         fused = self.fuse_eval(outputs, batch_input, binary_scores)
         outputs.update(fused)
         outputs.update({"mask_cls_results": mask_cls_results, "binary_pred": binary_pred})
