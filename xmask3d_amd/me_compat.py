@@ -31,6 +31,95 @@ import torch.nn as nn
 from . import ops
 
 
+# ----------------------------------------------------------------------------- autograd (training) path
+class _SpconvFn(torch.autograd.Function):
+    """out = sum_k feats[nbr[k]] @ kernel[k];  dgrad = the same kernel over the inverse map with kernel[k]^T,
+    wgrad = xm3d_spconv_bwd_weight (replaces ME's conv backward, reached from loss.backward() run/train.py:537)."""
+
+    @staticmethod
+    def forward(ctx, feats, kernel3, cm, key, n_out):
+        ts_in, ts_out, ks, transposed = key
+        identity = ks == 1 and ts_in == ts_out
+        nbr = None if identity else cm.kernel_map(*key)
+        K, cin, cout = kernel3.shape
+        tiles = cm.tiles(*key) if ops.mfma_eligible(cin, cout) else None
+        ctx.save_for_backward(feats, kernel3)
+        ctx.cm, ctx.key, ctx.identity = cm, key, identity
+        return ops.spconv_fwd(feats, kernel3, nbr, n_out, order=cm.order(ts_out), tiles=tiles)
+
+    @staticmethod
+    def backward(ctx, gout):
+        feats, kernel3 = ctx.saved_tensors
+        cm, key = ctx.cm, ctx.key
+        ts_in = key[0]
+        gout = gout.contiguous()
+        K, cin, cout = kernel3.shape
+        gin = gw = None
+        if ctx.needs_input_grad[0]:
+            wt = kernel3.transpose(1, 2).contiguous()
+            if ctx.identity:
+                nbr_t, tiles_t = None, (cm.tiles(*key) if ops.mfma_eligible(cout, cin) else None)
+            else:
+                nbr_t = cm.inverse_map(*key)
+                tiles_t = cm.tiles(*key, inverse=True) if ops.mfma_eligible(cout, cin) else None
+            gin = ops.spconv_fwd(gout, wt, nbr_t, feats.shape[0], order=cm.order(ts_in), tiles=tiles_t)
+        if ctx.needs_input_grad[1]:
+            gw = ops.spconv_bwd_weight(feats, gout, None if ctx.identity else cm.kernel_map(*key), K)
+        return gin, gw, None, None, None
+
+
+def sync_moments(s, ss, n, group=None):
+    """(sum, sumsq, count) -> (mean, biased var, total count); all-reduced over `group` when given.
+    Pure tensor math so the reduction logic is testable on CPU with gloo."""
+    import torch.distributed as dist
+
+    packed = torch.cat([s.double(), ss.double(), torch.as_tensor([float(n)], dtype=torch.float64, device=s.device)])
+    if group is not None:
+        dist.all_reduce(packed, group=None if group is True else group)
+    c = s.numel()
+    total = packed[-1]
+    mean = packed[:c] / total
+    var = (packed[c:2 * c] / total - mean * mean).clamp_min(0.0)
+    return mean, var, total
+
+
+class _BatchNormFn(torch.autograd.Function):
+    """training-mode BatchNorm over rows with optional cross-rank statistics (MinkowskiBatchNorm / SyncBatchNorm)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, group):
+        s, ss = ops.bn_stats(x)
+        mean, var, total = sync_moments(s, ss, x.shape[0], group)
+        invstd = torch.rsqrt(var + eps)
+        w = weight.double() if weight is not None else torch.ones_like(invstd)
+        scale = (invstd * w).float()
+        shift = (-mean * invstd * w).float()
+        if bias is not None:
+            shift = shift + bias
+        y = ops.affine_act(x, scale.contiguous(), shift.contiguous())
+        ctx.save_for_backward(x, weight, mean.float(), invstd.float())
+        ctx.group, ctx.total = group, float(total)
+        ctx.mark_non_differentiable(mean, var, total)
+        return y, mean, var, total
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv, _gt):
+        import torch.distributed as dist
+
+        x, weight, mean, invstd = ctx.saved_tensors
+        xhat = (x - mean) * invstd
+        sum_dy, sum_dy_xhat = gy.sum(0), (gy * xhat).sum(0)
+        gw = sum_dy_xhat if weight is not None else None
+        gb = sum_dy
+        if ctx.group is not None:
+            red = torch.cat([sum_dy, sum_dy_xhat])
+            dist.all_reduce(red, group=None if ctx.group is True else ctx.group)
+            sum_dy, sum_dy_xhat = red[: sum_dy.numel()], red[sum_dy.numel():]
+        w = weight if weight is not None else torch.ones_like(invstd)
+        gx = (w * invstd) * (gy - sum_dy / ctx.total - xhat * (sum_dy_xhat / ctx.total))
+        return gx, gw, gb, None, None
+
+
 # ----------------------------------------------------------------------------- tensors
 class _PendingConv:
     def __init__(self, feats, kernel3, packed, nbr, order, n_out, tiles=None):
@@ -124,6 +213,8 @@ class SparseTensor:
 def _add(a: SparseTensor, b: SparseTensor) -> SparseTensor:
     if a.coordinate_manager is not b.coordinate_manager or a.tensor_stride != b.tensor_stride:
         raise RuntimeError("adding SparseTensors that live on different coordinate maps")
+    if torch.is_grad_enabled():
+        return a._like(a.F + b.F)
     if a._pending is not None and a._pending.residual is None and not a._pending.relu:
         a._pending.residual = b.F
         return a
@@ -200,9 +291,12 @@ class _ConvBase(nn.Module):
         ts_out = self._strides(ts_in)
         feats = x.F
         if torch.is_grad_enabled() and (feats.requires_grad or self.kernel.requires_grad):
-            raise NotImplementedError(
-                "sparse-conv backward (xm3d_spconv_bwd_data / _bwd_weight) is not part of this build yet; "
-                "run the 3D backbone under torch.no_grad()")
+            k3 = self._kernel3()
+            out = _SpconvFn.apply(feats, k3 if k3.is_contiguous() else k3.contiguous(), cm,
+                                  (ts_in, ts_out, self.kernel_size, self.transposed), cm.num(ts_out))
+            if self.bias is not None:
+                out = out + self.bias
+            return SparseTensor(out, tensor_stride=ts_out, coordinate_manager=cm)
         k3 = self._kernel3().detach()
         if not k3.is_contiguous():
             k3 = k3.contiguous()
@@ -262,20 +356,28 @@ class MinkowskiBatchNorm(nn.Module):
                     p.scale, p.shift = s0 * scale, b0 * scale + shift
                 return x
             return x._like(pending=_PendingAffine(x.F, scale, shift))
+        return self._batch_stats_forward(x, None)
+
+    def _batch_stats_forward(self, x, group):
+        bn = self.bn
         feats = x.F
-        n = feats.shape[0]
-        s, ss = ops.bn_stats(feats)
-        mean = s / max(n, 1)
-        var = (ss / max(n, 1) - mean * mean).clamp_min(0.0)
+        if torch.is_grad_enabled():
+            y, mean, var, total = _BatchNormFn.apply(feats, bn.weight if bn.affine else None, bn.bias if bn.affine else None,
+                                                     bn.eps, group)
+            out = x._like(y)
+        else:
+            s, ss = ops.bn_stats(feats)
+            mean, var, total = sync_moments(s, ss, feats.shape[0], group)
+            scale, shift = self._scale_shift(mean, var)
+            out = x._like(pending=_PendingAffine(feats, scale, shift))
         if self.training and bn.track_running_stats:
             with torch.no_grad():
-                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                unbiased = var * (n / max(n - 1, 1))
-                bn.running_mean.mul_(1 - m).add_(mean.float(), alpha=m)
-                bn.running_var.mul_(1 - m).add_(unbiased.float(), alpha=m)
+                m_ = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
+                unbiased = var * (total / (total - 1.0).clamp_min(1.0))
+                bn.running_mean.mul_(1 - m_).add_(mean.float(), alpha=m_)
+                bn.running_var.mul_(1 - m_).add_(unbiased.float(), alpha=m_)
                 bn.num_batches_tracked += 1
-        scale, shift = self._scale_shift(mean, var)
-        return x._like(pending=_PendingAffine(feats, scale, shift))
+        return out
 
 
 class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
@@ -299,24 +401,7 @@ class MinkowskiSyncBatchNorm(MinkowskiBatchNorm):
 
         if not (self.training and dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1):
             return super().forward(x)
-        bn = self.bn
-        feats = x.F
-        s, ss = ops.bn_stats(feats)
-        packed = torch.cat([s, ss, torch.tensor([float(feats.shape[0])], dtype=torch.float64, device=feats.device)])
-        dist.all_reduce(packed)  # one fused (2C+1)-double all-reduce per layer
-        c = feats.shape[1]
-        n = packed[-1]
-        mean = packed[:c] / n
-        var = (packed[c:2 * c] / n - mean * mean).clamp_min(0.0)
-        if bn.track_running_stats:
-            with torch.no_grad():
-                m = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked + 1)
-                unbiased = var * (n / (n - 1).clamp_min(1))
-                bn.running_mean.mul_(1 - m).add_(mean.float(), alpha=m)
-                bn.running_var.mul_(1 - m).add_(unbiased.float(), alpha=m)
-                bn.num_batches_tracked += 1
-        scale, shift = self._scale_shift(mean, var)
-        return x._like(pending=_PendingAffine(feats, scale, shift))
+        return self._batch_stats_forward(x, True)  # one fused (2C+1)-double all-reduce per layer (+ one in backward)
 
 
 class MinkowskiReLU(nn.Module):
@@ -325,6 +410,8 @@ class MinkowskiReLU(nn.Module):
         self.inplace = inplace
 
     def forward(self, x: SparseTensor) -> SparseTensor:
+        if torch.is_grad_enabled():
+            return x._like(torch.relu(x.F))
         if x._pending is not None:
             x._pending.relu = True  # relu is idempotent, folding twice is harmless
             return x

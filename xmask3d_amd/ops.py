@@ -257,6 +257,21 @@ def spconv_fwd(feats, kernel, nbr, n_out, order=None, scale=None, shift=None, re
     return out
 
 
+def spconv_bwd_weight(feats, gout, nbr, K):
+    """gW (K,Cin,Cout) = sum_o feats[nbr[k,o]]^T gout[o]  (nbr None = K=1 identity map)"""
+    _req(feats, torch.float32, "features", 2)
+    _req(gout, torch.float32, "grad_output", 2)
+    n_out, cout = gout.shape
+    cin = feats.shape[1]
+    if nbr is not None:
+        _req(nbr, torch.int32, "nbr", 2)
+        assert tuple(nbr.shape) == (K, n_out)
+    gw = torch.empty((K, cin, cout), dtype=torch.float32, device=feats.device)
+    check(lib().xm3d_spconv_bwd_weight(_ptr(feats), feats.shape[0], cin, _ptr(gout), n_out, cout, _ptr(nbr), K, _ptr(gw),
+                                       _stream()), "xm3d_spconv_bwd_weight")
+    return gw
+
+
 def bn_stats(x):
     """per-channel (sum, sumsq) in f64 over rows of an (n,c) f32 matrix."""
     _req(x, torch.float32, "x", 2)

@@ -62,6 +62,37 @@ def build_view_batch(sd: SceneOnDevice, view: int, voxelizer: Voxelizer, matrix=
             "label_2d": None, "labels_3d": None, "use_pure_3d": False}
 
 
+def build_train_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, seed=0, n_classes=15, ignore=(19, 20)):
+    """A training batch of several views (one sample = one view, dataset/data_loader.py:85-316, collated as
+    data_loader.py:319-357 / run/train.py:462-502): batch index in column 0, inds_reconstruct offset per sample, the random
+    voxel-coordinate offset of run/train.py:481, synthetic 2D/3D labels."""
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    coords, feats, inv, ori, xs, ys, imgs, l3d, bl3d, l2d, caps = [], [], [], [], [], [], [], [], [], [], []
+    base = 0
+    for b, v in enumerate(views):
+        vw = sd.views[v]
+        pts = sd.points[vw["idx"]].contiguous()
+        grid, inds, inverse = voxelizer.voxelize_device(pts)
+        c = torch.cat([torch.full((grid.shape[0], 1), b, dtype=torch.int32, device=sd.device), grid], 1)
+        coords.append(c)
+        feats.append((sd.colors[vw["idx"]][inds] / 127.5 - 1.0).float())
+        inv.append(inverse + base)
+        base += grid.shape[0]
+        ori.append(torch.cat([torch.full((pts.shape[0], 1), float(b), device=sd.device), pts.float()], 1))
+        xs.append(vw["x"]); ys.append(vw["y"]); imgs.append(vw["img"]); caps.append(vw["caption"])
+        lab = torch.randint(0, n_classes + 1, (pts.shape[0],), generator=g).to(sd.device)  # n_classes = ignore label
+        l3d.append(lab)
+        bl3d.append(torch.where(lab == n_classes, torch.full_like(lab, ignore[0]), (lab % 4 != 0).long()).float())
+        blocks = torch.randint(0, n_classes + 1, (8, 8), generator=g)
+        l2d.append(blocks.repeat_interleave(64, 0).repeat_interleave(64, 1).to(sd.device))
+    coords = torch.cat(coords)
+    coords[:, 1:] += torch.randint(0, 100, (1, 3), generator=g).int().to(sd.device)  # run/train.py:481
+    return {"sinput": ME.SparseTensor(torch.cat(feats).contiguous(), coords.contiguous()), "img": torch.cat(imgs),
+            "x_label": torch.cat(xs), "y_label": torch.cat(ys), "inds_reconstruct": torch.cat(inv), "ori_coords": torch.cat(ori),
+            "captions": tuple(caps), "labels_3d": torch.cat(l3d), "binary_label_3d": torch.cat(bl3d), "label_2d": torch.stack(l2d),
+            "binary_label_2d": None, "coords": coords}
+
+
 def nearest_index(query: torch.Tensor, ref: torch.Tensor, chunk=8192):
     """index into ref of the nearest reference point for every query point (exact, chunked)."""
     out = torch.empty(query.shape[0], dtype=torch.long, device=query.device)

@@ -22,8 +22,11 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+import numpy as np
+
 from . import ops
-from .clip_model import CategoryEmbed, MaskCLIP
+from .clip_model import CategoryEmbed
+from .criterion import Criterion, HungarianMatcher
 from .image_branch import FeatureExtractorBackbone, LdmImplicitCaptionerExtractor
 from .mask_head import (MaskFormerHead, MSDeformAttnPixelDecoder, ODISEMultiScaleMaskedTransformerDecoder, PooledMaskEmbed,
                         PseudoClassEmbed)
@@ -43,41 +46,6 @@ def ensemble_logits_with_labels(logits, labels, ensemble_method="max"):
         outs.append(chunk.max(dim=-1).values if ensemble_method == "max" else chunk.mean(dim=-1))
         start += n
     return torch.stack(outs, dim=-1)
-
-
-class FeatureMerger(nn.Module):
-    """models/utils/fuser.py:64-72"""
-
-    def __init__(self, feature_dim):
-        super().__init__()
-        self.linear = nn.Linear(feature_dim * 2, feature_dim)
-
-    def forward(self, X, Y):
-        return self.linear(torch.cat((X, Y), dim=1))
-
-
-class CriterionHeads(nn.Module):
-    """The members of the reference ``Criterion`` (models/utils/criterion.py:11-37) that own state or are
-    used at inference: fuser, fc1, fc2, clip, weight_dict.  The matching losses attach in train mode."""
-
-    def __init__(self, cfg, num_layers=9, class_weight=2.0, mask_weight=5.0, dice_weight=5.0):
-        super().__init__()
-        wd = {"loss_ce": class_weight, "loss_mask": mask_weight, "loss_dice": dice_weight}
-        aux = {}
-        for i in range(num_layers):
-            aux.update({f"{k}_{i}": v for k, v in wd.items()})
-        wd.update(aux)
-        lw = cfg.loss_weight
-        for k in ("loss_3d", "loss_3d_pure", "loss_explicit_contra", "loss_explicit_contra_3d", "loss_explicit_contra_2d_pre",
-                  "loss_binary"):
-            wd[k] = lw[k] if isinstance(lw, dict) else getattr(lw, k)
-        self.weight_dict = wd
-        self.fuser = FeatureMerger(feature_dim=768)
-        self.fc1, self.fc2 = nn.Identity(), nn.Identity()
-        self.ignore_label = cfg.ignore_label
-        self.mask_contra_3d = cfg.mask_contra_3d
-        self.cfg = cfg
-        self.clip = MaskCLIP(name=cfg.clip_name)
 
 
 class XMASK3d(nn.Module):
@@ -116,7 +84,10 @@ class XMASK3d(nn.Module):
                 mask_classification=True, num_classes=num_classes, num_queries=num_queries, nheads=8, dim_feedforward=2048,
                 dec_layers=9, pre_norm=False, enforce_input_project=False, mask_dim=256),
             input_shape=self.backbone.output_shape())
-        self.criterion = CriterionHeads(cfg)
+        self.criterion = Criterion(
+            num_layers=9, class_weight=2.0, mask_weight=5.0, dice_weight=5.0, num_classes=num_classes,
+            matcher=HungarianMatcher(cost_class=2.0, cost_mask=5.0, cost_dice=5.0, num_points=12544), eos_coef=0.1,
+            losses=["labels", "masks"], num_points=12544, oversample_ratio=3.0, importance_sample_ratio=0.75, cfg=cfg)
         self.category_head = CategoryEmbed(clip_model_name=self.criterion.clip, labels=[[l] for l in cfg.label],
                                            test_labels=[[l] for l in cfg.all_label], projection_dim=-1)
         self.clip_head = self.criterion.clip
@@ -215,8 +186,7 @@ class XMASK3d(nn.Module):
     # ------------------------------------------------------------------ forward
     def forward(self, batch_input):
         if self.training:
-            raise NotImplementedError(
-                "training branch (Criterion losses, xmask3d.py:182-305) is not part of this build yet; call model.eval()")
+            return self.forward_train(batch_input)
         sinput = batch_input["sinput"]
         dev = sinput.F.device
         img = batch_input["img"]
@@ -237,6 +207,55 @@ class XMASK3d(nn.Module):
         outputs.update(fused)
         outputs.update({"mask_cls_results": mask_cls_results, "binary_pred": binary_pred})
         return None, outputs
+
+    def forward_train(self, batch_input):
+        """models/xmask3d.py:182-305: Hungarian-matched mask losses (main + 9 aux), 3D CE losses on fused / pure-3D point
+        features, caption cosine losses, binary base/novel loss; returns weighted losses."""
+        cfg = self.cfg
+        sinput = batch_input["sinput"]
+        dev = sinput.F.device
+        img = batch_input["img"].to(dev)
+        B = img.shape[0]
+        inds = batch_input["inds_reconstruct"].to(dev)
+        batch_input = dict(batch_input)
+        for k in ("x_label", "y_label", "ori_coords", "labels_3d", "binary_label_3d"):
+            batch_input[k] = batch_input[k].to(dev)
+        pred_3d, cond, binary_scores = self.encode_3d(sinput, inds, B)
+        caption_embed = self.category_head.text_proj(self.category_head.clip.embed_text(batch_input["captions"]))
+        outputs = self.encode_2d(img, cond)
+        outputs["pred_3d"] = pred_3d
+        binary_pred = (torch.sigmoid(binary_scores) > 0.5).long()
+        label_2d = batch_input["label_2d"].to(dev)
+        targets = []
+        for i in range(B):  # one binary mask per label value present in the view (xmask3d.py:189-224)
+            values = torch.unique(label_2d[i])
+            targets.append({"labels": values.long(), "masks": (label_2d[i][None] == values.view(-1, 1, 1)).float()})
+        head = self.category_head(outputs, targets)
+        outputs.update(head)
+        outputs["pred_logits"] = self.cal_pred_logits(outputs)
+        for aux in outputs.get("aux_outputs", []):
+            aux.update(head)
+            aux["pred_logits"] = self.cal_pred_logits(aux)
+        losses, outputs = self.criterion(outputs, targets, batch_input)
+        cos = nn.CosineSimilarity()
+
+        def caption_loss(feats):
+            return (1 - cos(torch.stack([f.mean(0) for f in feats]), caption_embed)).mean()
+
+        if cfg.caption_contra:
+            losses["loss_explicit_contra"] = caption_loss(outputs["fused_pred_feature"])
+        if cfg.caption_contra_2d_pre:
+            losses["loss_explicit_contra_2d_pre"] = caption_loss(outputs["2d_pred_feature_pre"])
+        if cfg.caption_contra_3d:
+            losses["loss_explicit_contra_3d"] = caption_loss(outputs["pure3d_pred_feature"])
+        labels = batch_input["binary_label_3d"]
+        valid = ~torch.isin(labels, torch.tensor(self.ignore_label).to(labels))
+        self.binary_loss_func.pos_weight = self.binary_loss_func.pos_weight.to(dev)
+        losses["loss_binary"] = self.binary_loss_func(binary_scores[valid], labels[valid].reshape(-1, 1))
+        outputs["binary_pred"] = binary_pred
+        wd = self.criterion.weight_dict
+        losses = {k: v * wd[k] for k, v in losses.items() if k in wd}
+        return losses, outputs
 
     def fuse_eval(self, outputs, batch_input, binary_scores):
         cfg = self.cfg
