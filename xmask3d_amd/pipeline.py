@@ -62,6 +62,27 @@ def build_view_batch(sd: SceneOnDevice, view: int, voxelizer: Voxelizer, matrix=
             "label_2d": None, "labels_3d": None, "use_pure_3d": False}
 
 
+def build_scene_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, matrices=None):
+    """All (or some) views of a scene as ONE batch: views are independent until the vote, so they are collated like a
+    DataLoader batch (batch index in column 0 of coords / ori_coords, inds_reconstruct offset per view)."""
+    coords, feats, inv, ori, xs, ys, imgs, caps = [], [], [], [], [], [], [], []
+    base = 0
+    for b, v in enumerate(views):
+        vw = sd.views[v]
+        pts = sd.points[vw["idx"]].contiguous()
+        grid, inds, inverse = voxelizer.voxelize_device(pts, None if matrices is None else matrices[b])
+        coords.append(torch.cat([torch.full((grid.shape[0], 1), b, dtype=torch.int32, device=sd.device), grid], 1))
+        feats.append((sd.colors[vw["idx"]][inds] / 127.5 - 1.0).float())
+        inv.append(inverse + base)
+        base += grid.shape[0]
+        ori.append(torch.cat([torch.full((pts.shape[0], 1), float(b), device=sd.device), pts.float()], 1))
+        xs.append(vw["x"]); ys.append(vw["y"]); imgs.append(vw["img"]); caps.append(vw["caption"])
+    coords = torch.cat(coords).contiguous()
+    return {"sinput": ME.SparseTensor(torch.cat(feats).contiguous(), coords), "img": torch.cat(imgs), "x_label": torch.cat(xs),
+            "y_label": torch.cat(ys), "inds_reconstruct": torch.cat(inv), "ori_coords": torch.cat(ori), "captions": tuple(caps),
+            "coords": coords, "label_2d": None, "labels_3d": None, "use_pure_3d": False}
+
+
 def build_train_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, seed=0, n_classes=15, ignore=(19, 20)):
     """A training batch of several views (one sample = one view, dataset/data_loader.py:85-316, collated as
     data_loader.py:319-357 / run/train.py:462-502): batch index in column 0, inds_reconstruct offset per sample, the random
@@ -111,17 +132,18 @@ def _gate(logits, binary_pred, base, novel):
     return binary_pred * lb + (1 - binary_pred) * ln
 
 
-def postprocess_view(cfg, outputs, batch, with_ablations=True):
-    """-> class id per visible point for the fused / 2D-only / 3D-only predictions."""
+def postprocess_view(cfg, outputs, batch, with_ablations=True, s=0):
+    """-> class id per visible point of batch entry `s` for the fused / 2D-only / 3D-only predictions."""
     cs = cfg.category_split
     base, novel, allc = list(cs["base_category"]), list(cs["novel_category"]), list(cs["all_category"])
     text = F.normalize(outputs["text_embed"], dim=-1)
     scale = outputs["logit_scale"]
-    binary_pred = outputs["binary_pred"]
-    fused = F.normalize(torch.cat(outputs["fused_pred_feature"]), dim=-1)
+    sel = batch["ori_coords"][:, 0] == s
+    binary_pred = outputs["binary_pred"][sel]
+    fused = F.normalize(outputs["fused_pred_feature"][s], dim=-1)
     probs = (scale * (fused @ text.t())).softmax(dim=-1)
-    open_emb = torch.cat(outputs["final_pred_open_embedding"])
-    masks = torch.cat(outputs["final_mask_3d"])
+    open_emb = outputs["final_pred_open_embedding"][s]
+    masks = outputs["final_mask_3d"][s]
     if masks.shape[0] > 0:
         open_p = (scale * (F.normalize(open_emb, dim=-1) @ text.t())).softmax(dim=-1)
         overlap = torch.tensor([int(c in base) for c in allc], device=probs.device, dtype=probs.dtype)
@@ -134,35 +156,41 @@ def postprocess_view(cfg, outputs, batch, with_ablations=True):
     pred = _gate(probs, binary_pred, base, novel).argmax(1)
     if not with_ablations:
         return pred, None, None
-    f2d = torch.cat(outputs["2d_pred_feature"]).clone()
+    f2d = outputs["2d_pred_feature"][s].clone()
     empty = f2d.sum(1) == 0
     if bool(empty.any()) and not bool(empty.all()):
-        xyz = batch["ori_coords"][:, 1:]
+        xyz = batch["ori_coords"][sel][:, 1:]
         src = torch.nonzero(~empty)[:, 0]
         f2d[empty] = f2d[src[nearest_index(xyz[empty], xyz[src])]]
     pred2d = _gate(scale * (F.normalize(f2d, dim=-1) @ text.t()), binary_pred, base, novel).argmax(1)
-    f3d = F.normalize(torch.cat(outputs["pure3d_pred_feature"]), dim=-1)
+    f3d = F.normalize(outputs["pure3d_pred_feature"][s], dim=-1)
     pred3d = _gate(scale * (f3d @ text.t()), binary_pred, base, novel).argmax(1)
     return pred, pred2d, pred3d
 
 
 @torch.no_grad()
-def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, with_ablations=True):
-    """Loop over the views of one scene (batch 1 each, like the reference), vote, fill unseen points.
+def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, with_ablations=True, views_per_batch=None):
+    """All views of one scene -> per-point class votes -> arg-max, unseen points take the nearest seen point's label.
+    views_per_batch: how many views go through the model together (default: all of them, one forward per scene; 1 =
+    the reference's batch-1 loop, run/infer.py:428-482).  Per-view results do not depend on the grouping.
     matrices: optional list of 4x4 voxelisation transforms (otherwise drawn from np.random like the reference)."""
     voxelizer = voxelizer or default_voxelizer(cfg.voxel_size, sd.device)
     ncls = len(cfg.category_split["base_category"]) + len(cfg.category_split["novel_category"])
     votes = [torch.zeros((sd.n, ncls), dtype=torch.int32, device=sd.device) for _ in range(3 if with_ablations else 1)]
     seen = torch.zeros(sd.n, dtype=torch.bool, device=sd.device)
-    for v in range(len(sd.views)):
-        batch = build_view_batch(sd, v, voxelizer, None if matrices is None else matrices[v])
+    nv = len(sd.views)
+    step = views_per_batch or nv
+    for v0 in range(0, nv, step):
+        views = list(range(v0, min(v0 + step, nv)))
+        batch = build_scene_batch(sd, views, voxelizer, None if matrices is None else [matrices[v] for v in views])
         _, outputs = model(batch)
-        preds = postprocess_view(cfg, outputs, batch, with_ablations)
-        idx = sd.views[v]["idx"]
-        for vt, p in zip(votes, preds):
-            if p is not None:
-                vt.index_put_((idx, p), torch.ones_like(p, dtype=torch.int32), accumulate=True)
-        seen[idx] = True
+        for s, v in enumerate(views):
+            preds = postprocess_view(cfg, outputs, batch, with_ablations, s)
+            idx = sd.views[v]["idx"]
+            for vt, p in zip(votes, preds):
+                if p is not None:
+                    vt.index_put_((idx, p), torch.ones_like(p, dtype=torch.int32), accumulate=True)
+            seen[idx] = True
     out = []
     fill = None
     if not bool(seen.all()) and bool(seen.any()):

@@ -13,8 +13,9 @@ MI355X-first differences (results unchanged):
   * the <=50-iteration boolean-index loops of the eval fusion (xmask3d.py:421-451) are one HIP kernel
     (xm3d_mask_point_fuse) and the FeatureMerger is applied with a select instead of three index copies
   * frozen SD / CLIP nets can run in bf16 (``dense_dtype``), the reference is fp32 throughout
-Known reference quirks kept: eval fusion reads ``binary_scores`` of ALL points in the batch for every
-scene (xmask3d.py:363) - identical for the batch-1 inference the drivers use.
+Reference quirk NOT kept: its eval fusion reads ``binary_scores`` of ALL points in the batch for every scene and
+re-applies the sigmoid per scene (xmask3d.py:363), which only works for the batch-1 inference its drivers use; here
+each scene reads its own slice, so a batch of B views gives exactly the B batch-1 results.
 """
 from __future__ import annotations
 
@@ -278,9 +279,9 @@ class XMASK3d(nn.Module):
             cls = outputs["pred_logits"][s]
             m3d_full = m[:, x_label, y_label].sigmoid() > 0.5
             keep_full = m3d_full.sum(1) > 0
-            binary_scores = torch.sigmoid(binary_scores).view(1, -1)  # sic: re-applied per scene in the reference
+            scene_scores = torch.sigmoid(binary_scores[sel]).view(1, -1)
             cover = m3d_full.float()
-            bp = (binary_scores * cover).sum(1) / (cover.sum(1) + 1e-10)
+            bp = (scene_scores * cover).sum(1) / (cover.sum(1) + 1e-10)
             is_base = (bp > cfg.binary_2d_thresh).view(-1, 1)
             l_novel, l_base = cls.clone(), cls.clone()
             l_novel[:, base_cat + [num_classes]] = -1e10
