@@ -140,6 +140,16 @@ int xm3d_affine_act(const float* x, int64_t n, int32_t c, const float* scale, co
                     const float* residual, int32_t relu, float* out, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Fused GroupNorm (+SiLU) over NCHW activations (replaces nn.GroupNorm(32,C) [+ x*sigmoid(x)] inside the SD
+ * VAE/UNet blocks the extractor runs, models/modeling/meta_arch/ldm.py:386-490, and the GN of the projection
+ * bottlenecks, backbone/feature_extractor.py:40-47).  x, y: (B,C,H*W) contiguous, dtype 0 = f32, 1 = bf16;
+ * gamma/beta: (C) in the SAME dtype or NULL; silu: 0 = none, 1 = SiLU, 2 = ReLU; stats_ws: B*G*2 doubles of
+ * scratch.  y may alias x.
+ * ------------------------------------------------------------------------- */
+int xm3d_group_norm(const void* x, int32_t dtype, int64_t B, int32_t C, int32_t hw, int32_t G, const void* gamma,
+                    const void* beta, float eps, int32_t silu, void* y, double* stats_ws, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Multi-scale deformable attention (replaces the pybind module
  * MultiScaleDeformableAttention: third_party/Mask2Former/mask2former/modeling/
  * pixel_decoder/ops/src/vision.cpp:18-21, ms_deform_attn.h:25-66,

@@ -103,3 +103,20 @@ def test_mask_point_fuse_matches_reference_mask_mapper(dev, golden_dir):
         fused = p3d.clone()
         fused[covered] = torch.cat([feat[covered], p3d[covered]], 1) @ W.T + b
         np.testing.assert_allclose(fused.numpy(), g[f"fused{i}"], rtol=1e-4, atol=1e-5)
+
+
+@pytest.mark.parametrize("dtype,shape,act", [(torch.float32, (2, 64, 16, 24), 1), (torch.bfloat16, (3, 128, 32, 32), 1),
+                                            (torch.bfloat16, (1, 320, 64, 64), 0), (torch.float32, (2, 512, 8, 8), 2),
+                                            (torch.bfloat16, (2, 2560, 8, 8), 1), (torch.bfloat16, (1, 128, 256, 256), 1)])
+def test_fused_group_norm_matches_torch(dev, dtype, shape, act):
+    from xmask3d_amd import ops
+
+    torch.manual_seed(sum(shape))
+    x = (torch.randn(shape) * 2 + 0.3)
+    w, b = torch.rand(shape[1]) + 0.5, torch.randn(shape[1])
+    ref = torch.nn.functional.group_norm(x.to(dtype).float(), 32, w.to(dtype).float(), b.to(dtype).float(), 1e-6)
+    ref = ref * torch.sigmoid(ref) if act == 1 else (torch.relu(ref) if act == 2 else ref)
+    y = ops.group_norm(x.to(dev).to(dtype), 32, w.to(dev).to(dtype), b.to(dev).to(dtype), 1e-6, act)
+    assert y.dtype == dtype and y.shape == x.shape
+    tol = 1e-5 if dtype == torch.float32 else 2e-2  # bf16 output rounding
+    assert (y.float().cpu() - ref).abs().max().item() <= tol * max(ref.abs().max().item(), 1.0)

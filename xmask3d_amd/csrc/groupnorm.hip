@@ -1,0 +1,163 @@
+// Fused GroupNorm (+ optional SiLU) over NCHW activations, bf16 or f32 I/O, f32/f64 statistics.
+// Replaces, inside the frozen SD VAE / UNet and the projection bottlenecks, the library sequence
+// {row-wise moments, fused-params, elementwise affine, sigmoid, multiply} (GroupNorm(32,C) followed by swish:
+// ldm's ResnetBlock / ResBlock / SpatialTransformer, reached from models/modeling/meta_arch/ldm.py:386-490) by two
+// HBM-streaming passes:
+//   k_gn_stats : each workgroup reduces one <=16 Ki-element slice of one (sample, group) - contiguous in NCHW -
+//                with 16-byte loads, f32 lanes -> f64 wave/LDS reduction -> one f64 atomic pair per workgroup
+//   k_gn_apply : y = act((x - mean) * rstd * gamma[c] + beta[c]), act = none | SiLU (1) | ReLU (2), 16 bytes per lane, the second read of x
+//                mostly hits L2 / Infinity Cache for all but the 512x512 VAE maps
+// Algorithmic bytes: 3 * numel * sizeof(T) (two reads, one write).
+#include <hip/hip_bf16.h>
+
+#include "common.h"
+
+namespace xm3d {
+
+template <typename T>
+struct VecIO;
+template <>
+struct VecIO<float> {
+    static constexpr int N = 4;
+    __device__ static void load(const float* p, float (&v)[4]) {
+        const float4 t = *reinterpret_cast<const float4*>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    }
+    __device__ static void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
+    __device__ static float scalar(const float* p) { return *p; }
+};
+template <>
+struct VecIO<__hip_bfloat16> {
+    static constexpr int N = 8;
+    __device__ static void load(const __hip_bfloat16* p, float (&v)[8]) {
+        const uint4 t = *reinterpret_cast<const uint4*>(p);
+        const unsigned w[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            v[2 * i] = __uint_as_float(w[i] << 16);
+            v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
+        }
+    }
+    __device__ static void store(__hip_bfloat16* p, const float (&v)[8]) {
+        unsigned w[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const __hip_bfloat16 lo = __float2bfloat16(v[2 * i]), hi = __float2bfloat16(v[2 * i + 1]);
+            w[i] = unsigned(*reinterpret_cast<const unsigned short*>(&lo)) | (unsigned(*reinterpret_cast<const unsigned short*>(&hi)) << 16);
+        }
+        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
+    }
+    __device__ static float scalar(const __hip_bfloat16* p) { return __bfloat162float(*p); }
+};
+
+constexpr int GN_SLICE = 16384;  // elements per workgroup in the statistics pass
+
+// zeroing by kernel, not hipMemsetAsync: memset nodes captured into a HIP graph were observed not to take effect on
+// replay with this ROCm (stale statistics -> NaN), a kernel node always does
+__global__ void k_gn_zero(double* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0.0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_stats(const T* __restrict__ x, int64_t group_elems, int slices,
+                                                  double* __restrict__ stats) {
+    constexpr int N = VecIO<T>::N;
+    const int64_t bg = blockIdx.x / slices;
+    const int slice = blockIdx.x % slices;
+    const int64_t lo = int64_t(slice) * GN_SLICE;
+    const int64_t hi = (lo + GN_SLICE < group_elems) ? lo + GN_SLICE : group_elems;
+    const T* base = x + bg * group_elems;
+    float s = 0.f, ss = 0.f;
+    for (int64_t i = lo + int64_t(threadIdx.x) * N; i < hi; i += 256 * N) {
+        float v[N];
+        VecIO<T>::load(base + i, v);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            s += v[j];
+            ss = fmaf(v[j], v[j], ss);
+        }
+    }
+    double ds = s, dss = ss;
+    for (int off = 32; off > 0; off >>= 1) {
+        ds += __shfl_xor(ds, off);
+        dss += __shfl_xor(dss, off);
+    }
+    __shared__ double sm[8];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) {
+        sm[wave * 2] = ds;
+        sm[wave * 2 + 1] = dss;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(&stats[bg * 2], sm[0] + sm[2] + sm[4] + sm[6]);
+        atomicAdd(&stats[bg * 2 + 1], sm[1] + sm[3] + sm[5] + sm[7]);
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x, const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                  const double* __restrict__ stats, int64_t nvec, int C, int hw, int cg,
+                                                  float inv_elems, float eps, int silu, T* __restrict__ y) {
+    constexpr int N = VecIO<T>::N;
+    const int G = C / cg;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < nvec; e += stride) {
+        const int64_t elem = e * N;
+        const int64_t bc = elem / hw;  // (b*C + c): a vector never straddles channels (hw % N == 0)
+        const int c = int(bc % C);
+        const int64_t bg = (bc / C) * G + c / cg;
+        const double m = stats[bg * 2] * inv_elems;
+        const double var = stats[bg * 2 + 1] * inv_elems - m * m;
+        const float mean = float(m), rstd = rsqrtf(fmaxf(float(var), 0.f) + eps);
+        const float ga = gamma ? VecIO<T>::scalar(gamma + c) : 1.f, be = beta ? VecIO<T>::scalar(beta + c) : 0.f;
+        const float a = rstd * ga, b = be - mean * a;
+        float v[N];
+        VecIO<T>::load(x + elem, v);
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            float t = fmaf(v[j], a, b);
+            if (silu == 1) t = t / (1.f + __expf(-t));
+            else if (silu == 2) t = fmaxf(t, 0.f);
+            v[j] = t;
+        }
+        VecIO<T>::store(y + elem, v);
+    }
+}
+
+template <typename T>
+static int gn_launch(const void* x, int64_t B, int C, int hw, int G, const void* gamma, const void* beta, float eps, int silu,
+                     void* y, double* stats, hipStream_t s) {
+    const int cg = C / G;
+    const int64_t group_elems = int64_t(cg) * hw;
+    const int slices = int((group_elems + GN_SLICE - 1) / GN_SLICE);
+    const int nstat = int(B) * G * 2;
+    hipLaunchKernelGGL(k_gn_zero, dim3((nstat + 255) / 256), dim3(256), 0, s, stats, nstat);
+    hipLaunchKernelGGL(k_gn_stats<T>, dim3(unsigned(B * G * slices)), dim3(256), 0, s, static_cast<const T*>(x), group_elems, slices, stats);
+    const int64_t nvec = B * C * int64_t(hw) / VecIO<T>::N;
+    int64_t blocks = (nvec + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_gn_apply<T>, dim3(unsigned(blocks)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(gamma),
+                       static_cast<const T*>(beta), stats, nvec, C, hw, cg, 1.0f / float(group_elems), eps, silu, static_cast<T*>(y));
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+}  // namespace xm3d
+
+using namespace xm3d;
+
+extern "C" int xm3d_group_norm(const void* x, int32_t dtype, int64_t B, int32_t C, int32_t hw, int32_t G, const void* gamma,
+                               const void* beta, float eps, int32_t silu, void* y, double* stats_ws, void* stream) {
+    XM3D_REQUIRE(B >= 0 && C >= 1 && hw >= 1 && G >= 1 && C % G == 0, "group_norm: bad shape B=%lld C=%d hw=%d G=%d", (long long)B, C, hw, G);
+    XM3D_REQUIRE(dtype == 0 || dtype == 1, "group_norm: dtype must be 0 (f32) or 1 (bf16)");
+    if (B == 0) return XM3D_OK;
+    XM3D_REQUIRE(x && y && stats_ws, "group_norm: null pointer");
+    const int N = dtype == 0 ? 4 : 8;
+    XM3D_REQUIRE(hw % N == 0, "group_norm: H*W=%d must be a multiple of %d", hw, N);
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "group_norm: x/y must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    if (dtype == 0) return gn_launch<float>(x, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
+    return gn_launch<__hip_bfloat16>(x, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
+}

@@ -24,7 +24,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .sd_model import AutoencoderKL, UNetModel
+from .sd_model import ACT_NONE, ACT_RELU, AutoencoderKL, UNetModel, gn_act
 
 SCALE_FACTOR = 0.18215
 # sqrt(alphas_cumprod[0]) and sqrt(1 - alphas_cumprod[0]) of the "ldm_linear" schedule
@@ -187,8 +187,7 @@ class _ConvGN(nn.Conv2d):
         self._relu = relu
 
     def forward(self, x):
-        x = self.norm(super().forward(x))
-        return F.relu_(x) if self._relu else x
+        return gn_act(self.norm, super().forward(x), ACT_RELU if self._relu else ACT_NONE)
 
 
 class GNBottleneck(nn.Module):

@@ -289,6 +289,28 @@ def affine_act(x, scale=None, shift=None, residual=None, relu=False, out=None):
     return out
 
 
+# ---------------------------------------------------------------- fused GroupNorm(+SiLU)
+def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False):
+    """NCHW (or (B,C,L)) f32/bf16 device tensor -> same shape/dtype; statistics in f64, math in f32.
+    silu: False/0 none, True/1 SiLU, 2 ReLU fused after the affine."""
+    if not x.is_cuda:
+        raise RuntimeError("group_norm: ROCm device tensor required (no CPU path)")
+    if x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"group_norm: unsupported dtype {x.dtype}")
+    if not x.is_contiguous():
+        x = x.contiguous()
+    B, C = x.shape[0], x.shape[1]
+    hw = x.numel() // max(B * C, 1)
+    for t in (weight, bias):
+        if t is not None and (t.dtype != x.dtype or not t.is_contiguous() or t.numel() != C):
+            raise TypeError("group_norm: weight/bias must be contiguous (C,) tensors of the input dtype")
+    y = torch.empty_like(x)
+    stats = torch.empty(B * num_groups * 2, dtype=torch.float64, device=x.device)
+    check(lib().xm3d_group_norm(_ptr(x), 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups, _ptr(weight), _ptr(bias),
+                                float(eps), int(silu), _ptr(y), _ptr(stats), _stream()), "xm3d_group_norm")
+    return y
+
+
 # ---------------------------------------------------------------- deformable attention
 def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
     _req(value, torch.float32, "value", 4)
