@@ -180,6 +180,12 @@ int xm3d_mask_point_fuse(const uint8_t* masks, int32_t Q, int32_t Hm, int32_t Wm
                          const int64_t* y, int64_t n, const float* embed, int32_t C, float* feat2d,
                          int32_t* count, void* stream);
 
+/* ---------------------------------------------------------------------------
+ * Exact 1-nearest-neighbour index (replaces sklearn.neighbors.KDTree(...).query(k=1) in run/infer.py:523-553,
+ * :682-694): query (n,3) f32, ref (m,3) f32, out (n) i64 = arg-min squared distance, lowest index on ties.
+ * ------------------------------------------------------------------------- */
+int xm3d_nearest_index(const float* query, int64_t n, const float* ref, int64_t m, int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -120,3 +120,21 @@ def test_fused_group_norm_matches_torch(dev, dtype, shape, act):
     assert y.dtype == dtype and y.shape == x.shape
     tol = 1e-5 if dtype == torch.float32 else 2e-2  # bf16 output rounding
     assert (y.float().cpu() - ref).abs().max().item() <= tol * max(ref.abs().max().item(), 1.0)
+
+
+def test_nearest_index_is_exact(dev):
+    from xmask3d_amd import ops
+
+    torch.manual_seed(0)
+    ref = torch.rand(5000, 3) * 4
+    q = torch.rand(3001, 3) * 4
+    q[:10] = ref[100:110]  # exact hits
+    ref[4000] = ref[7]  # duplicate reference point: the lower index must win
+    q[10] = ref[7]
+    got = ops.nearest_index(q.to(dev), ref.to(dev)).cpu()
+    d = torch.cdist(q.double(), ref.double())
+    assert (d.gather(1, got[:, None])[:, 0] <= d.min(1).values + 1e-9).all()
+    assert got[:10].tolist() == list(range(100, 110)) and int(got[10]) == 7
+    assert ops.nearest_index(q[:0].to(dev), ref.to(dev)).shape == (0,)
+    one = ops.nearest_index(q.to(dev), ref[:1].to(dev))
+    assert (one == 0).all()

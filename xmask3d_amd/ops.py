@@ -359,3 +359,15 @@ def mask_point_fuse(masks_u8, x_label, y_label, embed):
     check(lib().xm3d_mask_point_fuse(_ptr(masks_u8), Q, Hm, Wm, _ptr(x_label), _ptr(y_label), n, _ptr(embed), C, _ptr(feat),
                                      _ptr(cnt), _stream()), "xm3d_mask_point_fuse")
     return feat, cnt
+
+
+# ---------------------------------------------------------------- nearest neighbour
+def nearest_index(query, ref):
+    """(n,3) f32, (m,3) f32 -> (n,) i64 index of the nearest reference point (exact, lowest index on ties)."""
+    _req(query, torch.float32, "query", 2)
+    _req(ref, torch.float32, "ref", 2)
+    if query.shape[1] != 3 or ref.shape[1] != 3:
+        raise RuntimeError("nearest_index works on 3-D points")
+    out = torch.empty(query.shape[0], dtype=torch.int64, device=query.device)
+    check(lib().xm3d_nearest_index(_ptr(query), query.shape[0], _ptr(ref), ref.shape[0], _ptr(out), _stream()), "xm3d_nearest_index")
+    return out

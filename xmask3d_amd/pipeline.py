@@ -17,6 +17,7 @@ import torch
 import torch.nn.functional as F
 
 from . import me_compat as ME
+from . import ops
 from . import synthetic
 from .voxelizer import Voxelizer
 
@@ -114,15 +115,9 @@ def build_train_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, seed=0, n_
             "binary_label_2d": None, "coords": coords}
 
 
-def nearest_index(query: torch.Tensor, ref: torch.Tensor, chunk=8192):
-    """index into ref of the nearest reference point for every query point (exact, chunked)."""
-    out = torch.empty(query.shape[0], dtype=torch.long, device=query.device)
-    r2 = (ref * ref).sum(1)[None]
-    for s in range(0, query.shape[0], chunk):
-        q = query[s:s + chunk]
-        d = (q * q).sum(1)[:, None] + r2 - 2.0 * (q @ ref.T)
-        out[s:s + chunk] = d.argmin(1)
-    return out
+def nearest_index(query: torch.Tensor, ref: torch.Tensor):
+    """index into ref of the nearest reference point for every query point (exact; xm3d_nearest_index)"""
+    return ops.nearest_index(query.float().contiguous(), ref.float().contiguous())
 
 
 def _gate(logits, binary_pred, base, novel):
