@@ -82,7 +82,11 @@ def spconv_roofline(dev):
     flop = 2.0 * pairs * cin * cout
     gs_bytes = pairs * (cin + cout) * 4 + pairs * 8 + 27 * cin * cout * 4
     return {"kernel": "xm3d::k_spconv_tiles<6>", "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF,
-            "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "traffic": None,
+            "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
+            # HBM-side bytes per launch from rocprofv3 PMC passes on `bench.py --roofline-only` (profiles/r01_roofline_spconv_pmc.txt):
+            # FETCH_SIZE 207164 KiB + WRITE_SIZE 40130 KiB; algorithmic gather+scatter model below for comparison
+            "traffic": 253.2e6, "algorithmic_bytes_gather_scatter": gs_bytes,
+            "algorithmic_bytes_compulsory": (2 * n * cin + 27 * cin * cout) * 4 + 8 * pairs,
             "avg_launch_us": ms * 1e3, "pairs": pairs, "voxels": n, "cin": cin, "cout": cout,
             "gather_scatter_GBps": gs_bytes / (ms * 1e-3) / 1e9}
 
@@ -97,6 +101,8 @@ def main():
     ap.add_argument("--views-per-batch", type=int, default=0, help="views per forward (0 = all views of the scene; 1 = reference loop)")
     ap.add_argument("--no-graph", action="store_true", help="launch the dense branch eagerly instead of replaying a HIP graph")
     ap.add_argument("--faithful-dead-compute", action="store_true", help="also run what the reference computes and discards")
+    ap.add_argument("--roofline-only", action="store_true",
+                    help="only the kernel-level roofline run of k_spconv_tiles (the command profiles/ rocprof summaries are taken on)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -114,6 +120,10 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=dev)
+
+    if args.roofline_only:
+        print(json.dumps({"roofline": spconv_roofline(dev)}))
+        return
 
     import __graft_entry__
 
