@@ -1,0 +1,137 @@
+"""Train / infer drivers: the counterparts of /root/reference/run/train.py (main_worker :126-393, train_net :403-878)
+and run/infer.py (validate :338-911) on synthetic ScanNet-shaped scenes (no dataset offline).
+
+Kept from the reference: one process per GPU, ``dist_backend`` from the yaml ("nccl" == RCCL on ROCm), DDP with
+``find_unused_parameters=True``, MinkowskiSyncBatchNorm when the per-GPU batch is < 4 (train.py:185-187), AdamW with the two
+parameter groups of train.py:152-169 (3D nets at lr_3d, everything trainable else at lr_others, frozen SD/CLIP skipped),
+cosine / poly LR per iteration (train.py:575-586), checkpoint ``model/model_last.pth.tar`` every epoch (train.py:354-390),
+metrics all-reduced as SUMs (train.py:640-652, infer.py:717-726).
+Changed on purpose: no ``torch.cuda.empty_cache()`` per iteration (train.py:842), the twelve metric all-reduces are one
+coalesced tensor, scene post-processing stays on the device (pipeline.py).
+"""
+from __future__ import annotations
+
+import os
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import checkpoint as ckpt_io
+from . import me_compat as ME
+from . import metrics, pipeline, synthetic
+from .xmask3d import XMASK3d
+
+
+def setup_distributed(cfg):
+    rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=cfg.dist_backend, device_id=dev)
+    return rank, world, dev
+
+
+def build_optimizer(model, cfg):
+    core = model.module if hasattr(model, "module") else model
+    g3d, rest = [], []
+    for name, p in core.named_parameters():
+        if not p.requires_grad or "ldm_extractor.ldm" in name or "clip.clip" in name:
+            continue
+        (g3d if ("pc_decoder" in name or "pc_binary_head" in name) else rest).append(p)
+    return torch.optim.AdamW([{"params": g3d, "lr": cfg.lr_3d}, {"params": rest, "lr": cfg.lr_others}])
+
+
+def synthetic_labels(scene, n_classes=19, seed=0):
+    """deterministic per-point ground truth for the synthetic room: class by height band x quadrant"""
+    p = scene.points
+    band = np.clip((p[:, 2] / 2.6 * 4).astype(int), 0, 3)
+    quad = (p[:, 0] > 3.0).astype(int) * 2 + (p[:, 1] > 2.5).astype(int)
+    return torch.from_numpy(((band * 4 + quad + seed) % n_classes).astype(np.int64))
+
+
+def train(cfg, epochs=1, iters_per_epoch=4, views_per_gpu=2, save_path=None, resume=None, log=print):
+    rank, world, dev = setup_distributed(cfg)
+    torch.manual_seed(cfg.manual_seed)
+    np.random.seed(cfg.manual_seed + rank)
+    model = XMASK3d(cfg).to(dev)
+    if world > 1:
+        if views_per_gpu < 4:
+            ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
+            torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)
+    opt = build_optimizer(model, cfg)
+    start_epoch, best = 0, 0.0
+    if resume:
+        info = ckpt_io.load_checkpoint(resume, model, opt, map_location=dev)
+        start_epoch, best = info["start_epoch"], info["best_iou"]
+    sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
+    vox = pipeline.default_voxelizer(cfg.voxel_size, dev)
+    max_iter = epochs * iters_per_epoch
+    core = model.module if world > 1 else model
+    K = cfg.classes
+    for epoch in range(start_epoch, epochs):
+        model.train()
+        meter = metrics.AverageMeter()
+        t0 = time.perf_counter()
+        for i in range(iters_per_epoch):
+            it = epoch * iters_per_epoch + i
+            sched = metrics.cosine_learning_rate if cfg.learning_rate_type == "cosine" else metrics.poly_learning_rate
+            opt.param_groups[0]["lr"] = sched(cfg.lr_3d, it, max_iter)
+            opt.param_groups[1]["lr"] = sched(cfg.lr_others, it, max_iter)
+            views = [(it * views_per_gpu * world + rank * views_per_gpu + j) % len(sd.views) for j in range(views_per_gpu)]
+            batch = pipeline.build_train_batch(sd, views, vox, seed=cfg.manual_seed + it * world + rank)
+            losses, outputs = model(batch)
+            loss = sum(losses.values())
+            opt.zero_grad(set_to_none=True)
+            loss.backward()
+            opt.step()
+            with torch.no_grad():  # train-mIoU bookkeeping: one coalesced all-reduce instead of twelve (train.py:624-652)
+                text = torch.nn.functional.normalize(torch.cat([outputs["text_embed"], outputs["null_embed"]]), dim=-1)
+                feat = torch.nn.functional.normalize(torch.cat(outputs["fused_pred_feature"]), dim=-1)
+                pred = (outputs["logit_scale"] * feat @ text.t()).argmax(1)
+                stats = torch.stack(metrics.intersection_and_union(pred, batch["labels_3d"], K, (cfg.ignore_label,)))
+                red = torch.cat([stats.reshape(-1), loss.detach().reshape(1)])
+                if world > 1:
+                    dist.all_reduce(red)
+                meter.update(float(red[-1]) / world)
+            if rank == 0:
+                log(f"epoch {epoch} iter {i} loss {meter.val:.4f} lr {opt.param_groups[0]['lr']:.2e}/{opt.param_groups[1]['lr']:.2e}")
+        if rank == 0 and save_path:
+            ckpt_io.save_checkpoint(os.path.join(save_path, "model", "model_last.pth.tar"), core, opt, epoch + 1, best)
+        if rank == 0:
+            log(f"epoch {epoch}: {iters_per_epoch / (time.perf_counter() - t0):.2f} iters/s, mean loss {meter.avg:.4f}")
+    return model
+
+
+@torch.no_grad()
+def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, log=print):
+    """-> dict of open-vocabulary scores for the fused / 2D / 3D predictions (infer.py:696-911 bookkeeping)."""
+    rank, world, dev = setup_distributed(cfg)
+    if model is None:
+        torch.manual_seed(cfg.manual_seed)
+        model = XMASK3d(cfg).to(dev)
+        if resume:
+            ckpt_io.load_checkpoint(resume, model, eval=True, map_location=dev)
+    model = (model.module if hasattr(model, "module") else model).eval().set_dense_dtype(dense_dtype).enable_dense_graph()
+    K = cfg.test_classes
+    names = ("fused", "2d", "3d")
+    acc = torch.zeros(3, 3, K, device=dev)
+    for s in range(rank, scenes, world):  # DistributedSampler(shuffle=False) partition
+        scene = synthetic.scene_s1(seed=cfg.manual_seed + s)
+        sd = pipeline.SceneOnDevice(scene, dev)
+        np.random.seed(cfg.manual_seed + s)
+        preds = pipeline.infer_scene(model, sd, cfg)
+        gt = synthetic_labels(scene, K, s).to(dev)
+        for j, p in enumerate(preds):
+            acc[j] += torch.stack(metrics.intersection_and_union(p, gt, K, tuple(cfg.test_ignore_label)))
+    if world > 1:
+        dist.all_reduce(acc)  # nine SUM all-reduces of the reference (infer.py:717-726) as one
+    cs = cfg.category_split
+    out = {n: metrics.open_vocab_scores(acc[j, 0], acc[j, 1], cs["base_category"], cs["novel_category"]) for j, n in enumerate(names)}
+    if rank == 0:
+        for n, v in out.items():
+            log(f"{n}: hIoU {v['hIoU']:.4f} mIoU_base {v['mIoU_base']:.4f} mIoU_novel {v['mIoU_novel']:.4f}")
+    return out
