@@ -103,23 +103,47 @@ class LdmExtractor(nn.Module):
         n = len(self.encoder_block_indices) + len(self.unet_block_indices) + len(self.decoder_block_indices)
         return [[i] for i in range(n)]
 
-    def forward(self, img, cond_inputs, cond_emb):
-        """img (B,3,512,512) in [0,1]; cond_inputs (B,77,768); cond_emb (B,1,1280) -> list of 8 feature maps."""
+    def encode(self, img):
+        """VAE encoder stage: img (B,3,H,W) in [0,1] -> (latent (B,4,H/8,W/8), tapped encoder features).  Independent of the
+        3D conditioning, so it can run concurrently with the sparse 3D branch."""
         ldm = self.ldm
         x = (img - ldm.pixel_mean.to(img.dtype)) / ldm.pixel_std.to(img.dtype)
         moments, enc_feats = ldm.encoder(x, taps=self.encoder_block_indices)
         moments = ldm.first_stage_model.quant_conv(moments)
-        latent = SCALE_FACTOR * moments[:, :4]  # posterior mean
+        return SCALE_FACTOR * moments[:, :4], enc_feats  # posterior mean
+
+    def decode_taps(self, latent):
+        z = self.ldm.first_stage_model.post_quant_conv(latent / SCALE_FACTOR)
+        return self.ldm.decoder(z, taps=self.decoder_block_indices, stop_after_taps=self.prune_dead_compute)[1]
+
+    def unet_taps(self, latent, cond_inputs, cond_emb):
         noise = self.shared_noise.to(latent.dtype)
         if noise.shape[2:] != latent.shape[2:]:
             noise = F.interpolate(noise, size=latent.shape[2:], mode="bicubic", align_corners=False)
         noisy = SQRT_AC0 * latent + SQRT_1M_AC0 * noise.expand_as(latent)
         t = torch.zeros(latent.shape[0], dtype=torch.long, device=latent.device)
-        _, unet_feats = ldm.unet(noisy, t, cond_inputs, cond_emb=cond_emb[:, 0], taps=self.unet_block_indices,
-                                 stop_after_taps=self.prune_dead_compute)
-        z = ldm.first_stage_model.post_quant_conv(latent / SCALE_FACTOR)
-        _, dec_feats = ldm.decoder(z, taps=self.decoder_block_indices, stop_after_taps=self.prune_dead_compute)
+        return self.ldm.unet(noisy, t, cond_inputs, cond_emb=cond_emb[:, 0], taps=self.unet_block_indices,
+                             stop_after_taps=self.prune_dead_compute)[1]
+
+    def from_latent(self, latent, enc_feats, cond_inputs, cond_emb, fork_stream=None):
+        """UNet taps and VAE-decoder taps from the latent.  The two are independent: with `fork_stream` (graph capture)
+        the decoder is enqueued on that stream and joined afterwards, so the captured graph runs them side by side."""
+        if fork_stream is not None:
+            cur = torch.cuda.current_stream()
+            fork_stream.wait_stream(cur)
+            with torch.cuda.stream(fork_stream):
+                dec_feats = self.decode_taps(latent)
+            unet_feats = self.unet_taps(latent, cond_inputs, cond_emb)
+            cur.wait_stream(fork_stream)
+        else:
+            unet_feats = self.unet_taps(latent, cond_inputs, cond_emb)
+            dec_feats = self.decode_taps(latent)
         return [*enc_feats, *unet_feats, *dec_feats]
+
+    def forward(self, img, cond_inputs, cond_emb):
+        """img (B,3,512,512) in [0,1]; cond_inputs (B,77,768); cond_emb (B,1,1280) -> list of 8 feature maps."""
+        latent, enc_feats = self.encode(img)
+        return self.from_latent(latent, enc_feats, cond_inputs, cond_emb)
 
 
 class PositionalLinear(nn.Module):
@@ -174,6 +198,10 @@ class LdmImplicitCaptionerExtractor(nn.Module):
     def forward(self, batched_inputs, prefix):
         cond, cond_emb = self.conditioning(prefix)
         img = batched_inputs["img"]
+        if "latent" in batched_inputs:  # VAE encoder already run (XMASK3d overlaps it with the 3D branch)
+            dt = batched_inputs["latent"].dtype
+            return self.ldm_extractor.from_latent(batched_inputs["latent"], batched_inputs["enc_feats"], cond.to(dt), cond_emb.to(dt),
+                                                  batched_inputs.get("fork_stream"))
         return self.ldm_extractor(img, cond.to(img.dtype), cond_emb.to(img.dtype))
 
 
@@ -243,14 +271,23 @@ class FeatureExtractorBackbone(nn.Module):
             out[name] = acc
         return out
 
-    def forward(self, img, imp_condition):
-        """img (B,3,H,W) in [0,1] (H=W=512 in every XMask3D config -> one 1x1 sliding window, feature_extractor.py:169-226)."""
+    def prepare(self, img):
         h, w = img.shape[-2:]
         if (h, w) != self.backbone_in_size:
             img = F.interpolate(img, size=self.backbone_in_size, mode="bicubic", align_corners=False)
+        return img
+
+    def forward(self, img, imp_condition, encoded=None, fork_stream=None):
+        """img (B,3,H,W) in [0,1] (H=W=512 in every XMask3D config -> one 1x1 sliding window, feature_extractor.py:169-226).
+        encoded = (latent, enc_feats) from ``feature_extractor.ldm_extractor.encode(prepare(img))`` skips the VAE encoder."""
+        h, w = img.shape[-2:]
+        img = self.prepare(img)
         # the frozen extractor runs natively in img.dtype (bf16 weights: no autocast casts, GroupNorm stays bf16 I/O);
         # the trainable fp32 projections run under autocast when the features are bf16
-        feats = self.feature_extractor(dict(img=img), imp_condition)
+        inputs = dict(img=img)
+        if encoded is not None:
+            inputs.update(latent=encoded[0], enc_feats=encoded[1], fork_stream=fork_stream)
+        feats = self.feature_extractor(inputs, imp_condition)
         low = img.dtype != torch.float32
         with torch.autocast(device_type=img.device.type, dtype=img.dtype if low else torch.bfloat16, enabled=low):
             if self.use_checkpoint and torch.is_grad_enabled():

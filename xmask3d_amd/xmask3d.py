@@ -59,6 +59,7 @@ class XMASK3d(nn.Module):
         self.dense_dtype = dense_dtype
         self.prune_dead_compute = prune_dead_compute
         self.channels_last = False
+        self.low_precision_heads = True
         self.register_buffer("_pixel_mean", torch.tensor(cfg.pixel_mean, dtype=torch.float32).view(1, 3, 1, 1), False)
         self.register_buffer("_pixel_std", torch.tensor(cfg.pixel_std, dtype=torch.float32).view(1, 3, 1, 1), False)
         self._dense_graphs = None
@@ -130,10 +131,8 @@ class XMASK3d(nn.Module):
         binary_scores = self.pc_binary_head(sinput)[inds_reconstruct, :]
         return pred_3d, cond, binary_scores
 
-    def encode_2d(self, img, imp_condition_input):
-        """img (B,3,H,W) 0..255 -> decoder outputs + mask-CLIP embeddings."""
-        dev = imp_condition_input.device
-        img = img.to(dev).float()
+    def normalize_images(self, img):
+        img = img.float()
         images = (img - self._pixel_mean) / self._pixel_std
         h, w = images.shape[-2:]
         ph, pw = (-h) % self.size_divisibility, (-w) % self.size_divisibility
@@ -142,15 +141,33 @@ class XMASK3d(nn.Module):
         images = images.to(self.dense_dtype)
         if self.channels_last:
             images = images.contiguous(memory_format=torch.channels_last)
-        feature = self.backbone(images, imp_condition_input)
-        outputs = self.sem_seg_head({k: v.float() for k, v in feature.items()})
+        return images
+
+    def encode_vae(self, img):
+        """VAE-encoder stage of the dense branch (no dependence on the 3D nets)."""
+        images = self.backbone.prepare(self.normalize_images(img))
+        return self.backbone.feature_extractor.ldm_extractor.encode(images)
+
+    def encode_2d(self, img, imp_condition_input, encoded=None, fork_stream=None):
+        """img (B,3,H,W) 0..255 -> decoder outputs + mask-CLIP embeddings."""
+        dev = imp_condition_input.device
+        img = img.to(dev).float()
+        images = self.normalize_images(img)
+        feature = self.backbone(images, imp_condition_input, encoded, fork_stream)
+        low = self.dense_dtype != torch.float32 and self.low_precision_heads and not torch.is_grad_enabled()
+        # bf16 mode: GEMMs of the pixel / transformer decoder run in bf16 too (the reference keeps them fp32; sampling in
+        # xm3d_msda_forward, LayerNorm statistics and the mask logits stay f32)
+        with torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=low):
+            outputs = self.sem_seg_head({k: v.float() for k, v in feature.items()})
+        for k in ("pred_masks", "mask_embed", "mask_pooled_features"):
+            outputs[k] = outputs[k].float()
         outputs["images"] = img / 255.0
         return outputs
 
-    def dense_forward(self, img, cond):
+    def dense_forward(self, img, cond, encoded=None, fork_stream=None):
         """The static-shape part of the eval forward (rows a8-a17): SD feature extractor, projections, pixel +
         transformer decoder, category logits, mask-CLIP.  img (B,3,H,W) 0..255 on device, cond (B,768)."""
-        outputs = self.encode_2d(img, cond)
+        outputs = self.encode_2d(img, cond, encoded, fork_stream)
         outputs.update(self.category_head(outputs))
         outputs["pred_logits"] = self.cal_pred_logits(outputs)
         clip_embed = self.clip_head(outputs["images"], outputs["pred_masks"])  # casts to the visual tower's dtype inside
@@ -163,26 +180,34 @@ class XMASK3d(nn.Module):
         self._dense_graphs = {} if on else None
         return self
 
-    def _dense_graphed(self, img, cond):
+    def _graphs_for(self, img, cond):
+        """Two HIP graphs per input shape: A = VAE encoder (independent of the 3D branch), B = everything after it with
+        the VAE decoder forked beside the UNet inside the capture."""
         key = (tuple(img.shape), img.dtype, self.dense_dtype, self.channels_last)
         entry = self._dense_graphs.get(key)
         if entry is None:
             s_img, s_cond = img.clone(), cond.clone()
-            side = torch.cuda.Stream()
+            side, fork = torch.cuda.Stream(), torch.cuda.Stream()
             side.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(side):
                 for _ in range(2):  # warm-up outside capture: MIOpen/hipBLASLt algorithm selection, constant caches
-                    self.dense_forward(s_img, s_cond)
+                    self.dense_forward(s_img, s_cond, self.encode_vae(s_img))
             torch.cuda.current_stream().wait_stream(side)
-            graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                s_out = self.dense_forward(s_img, s_cond)
-            entry = self._dense_graphs[key] = (graph, s_img, s_cond, s_out)
-        graph, s_img, s_cond, s_out = entry
-        s_img.copy_(img)
-        s_cond.copy_(cond)
-        graph.replay()
-        return dict(s_out)
+            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+            with torch.cuda.graph(ga):
+                s_enc = self.encode_vae(s_img)
+            with torch.cuda.graph(gb):
+                s_out = self.dense_forward(s_img, s_cond, s_enc, fork)
+            entry = self._dense_graphs[key] = dict(ga=ga, gb=gb, img=s_img, cond=s_cond, out=s_out, side=side, keep=(s_enc, fork))
+        return entry
+
+    def _dense_graphed(self, img, cond):
+        g = self._graphs_for(img, cond)
+        g["img"].copy_(img)
+        g["cond"].copy_(cond)
+        g["ga"].replay()
+        g["gb"].replay()
+        return dict(g["out"])
 
     # ------------------------------------------------------------------ forward
     def forward(self, batch_input):
@@ -193,12 +218,25 @@ class XMASK3d(nn.Module):
         img = batch_input["img"]
         B = img.shape[0]
         inds = batch_input["inds_reconstruct"].to(dev)
+        img = img.to(dev)
+        graphed = self._dense_graphs is not None and not torch.is_grad_enabled()
+        if graphed:
+            # VAE encoder graph on a side stream while the sparse 3D nets run on the current stream
+            cur = torch.cuda.current_stream()
+            dummy = torch.zeros(B, 768, device=dev)
+            g = self._graphs_for(img, dummy)
+            g["img"].copy_(img)
+            g["side"].wait_stream(cur)
+            with torch.cuda.stream(g["side"]):
+                g["ga"].replay()
         pred_3d, cond, binary_scores = self.encode_3d(sinput, inds, B)
         if not self.prune_dead_compute:  # the reference embeds the captions in eval and never uses the result
             self.category_head.clip.embed_text(batch_input["captions"])
-        img = img.to(dev)
-        if self._dense_graphs is not None and not torch.is_grad_enabled():
-            outputs = self._dense_graphed(img, cond)
+        if graphed:
+            g["cond"].copy_(cond)
+            cur.wait_stream(g["side"])
+            g["gb"].replay()
+            outputs = dict(g["out"])
         else:
             outputs = self.dense_forward(img, cond)
         outputs["pred_3d"] = pred_3d
