@@ -138,3 +138,8 @@ def test_nearest_index_is_exact(dev):
     assert ops.nearest_index(q[:0].to(dev), ref.to(dev)).shape == (0,)
     one = ops.nearest_index(q.to(dev), ref[:1].to(dev))
     assert (one == 0).all()
+    valid = torch.rand(5000) < 0.3
+    got = ops.nearest_index(q.to(dev), ref.to(dev), valid.to(dev)).cpu()
+    dm = d.clone()
+    dm[:, ~valid] = float("inf")
+    assert valid[got].all() and (dm.gather(1, got[:, None])[:, 0] <= dm.min(1).values + 1e-9).all()

@@ -10,7 +10,7 @@ namespace xm3d {
 constexpr int NN_TILE = 1024;
 
 __global__ __launch_bounds__(256) void k_nearest(const float* __restrict__ q, int64_t n, const float* __restrict__ r, int64_t m,
-                                                 int64_t* __restrict__ out) {
+                                                 const uint8_t* __restrict__ valid, int64_t* __restrict__ out) {
     __shared__ float4 tile[NN_TILE];
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -26,7 +26,8 @@ __global__ __launch_bounds__(256) void k_nearest(const float* __restrict__ q, in
         __syncthreads();
         for (int j = threadIdx.x; j < cnt; j += 256) {
             const float* p = r + 3 * (t0 + j);
-            tile[j] = make_float4(p[0], p[1], p[2], 0.f);
+            const bool ok = !valid || valid[t0 + j] != 0;  // masked-out reference points sit at +inf distance
+            tile[j] = ok ? make_float4(p[0], p[1], p[2], 0.f) : make_float4(INFINITY, INFINITY, INFINITY, 0.f);
         }
         __syncthreads();
         float tb = best;
@@ -53,11 +54,12 @@ __global__ __launch_bounds__(256) void k_nearest(const float* __restrict__ q, in
 
 using namespace xm3d;
 
-extern "C" int xm3d_nearest_index(const float* query, int64_t n, const float* ref, int64_t m, int64_t* out, void* stream) {
+extern "C" int xm3d_nearest_index(const float* query, int64_t n, const float* ref, int64_t m, const uint8_t* ref_valid,
+                                  int64_t* out, void* stream) {
     XM3D_REQUIRE(n >= 0 && m >= 1, "nearest_index: need n >= 0 queries and m >= 1 reference points (n=%lld m=%lld)", (long long)n, (long long)m);
     if (n == 0) return XM3D_OK;
     XM3D_REQUIRE(query && ref && out, "nearest_index: null pointer");
-    hipLaunchKernelGGL(k_nearest, dim3(unsigned((n + 255) / 256)), dim3(256), 0, as_stream(stream), query, n, ref, m, out);
+    hipLaunchKernelGGL(k_nearest, dim3(unsigned((n + 255) / 256)), dim3(256), 0, as_stream(stream), query, n, ref, m, ref_valid, out);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }

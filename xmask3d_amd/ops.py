@@ -362,12 +362,19 @@ def mask_point_fuse(masks_u8, x_label, y_label, embed):
 
 
 # ---------------------------------------------------------------- nearest neighbour
-def nearest_index(query, ref):
-    """(n,3) f32, (m,3) f32 -> (n,) i64 index of the nearest reference point (exact, lowest index on ties)."""
+def nearest_index(query, ref, ref_valid=None):
+    """(n,3) f32, (m,3) f32 -> (n,) i64 index of the nearest reference point (exact, lowest index on ties).
+    ref_valid (m,) uint8/bool: only reference points with a non-zero flag are considered."""
     _req(query, torch.float32, "query", 2)
     _req(ref, torch.float32, "ref", 2)
+    if ref_valid is not None:
+        if ref_valid.dtype == torch.bool:
+            ref_valid = ref_valid.to(torch.uint8)
+        _req(ref_valid, torch.uint8, "ref_valid", 1)
+        assert ref_valid.numel() == ref.shape[0]
     if query.shape[1] != 3 or ref.shape[1] != 3:
         raise RuntimeError("nearest_index works on 3-D points")
     out = torch.empty(query.shape[0], dtype=torch.int64, device=query.device)
-    check(lib().xm3d_nearest_index(_ptr(query), query.shape[0], _ptr(ref), ref.shape[0], _ptr(out), _stream()), "xm3d_nearest_index")
+    check(lib().xm3d_nearest_index(_ptr(query), query.shape[0], _ptr(ref), ref.shape[0], _ptr(ref_valid), _ptr(out), _stream()),
+          "xm3d_nearest_index")
     return out

@@ -68,9 +68,11 @@ def build_scene_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, matrices=N
     DataLoader batch (batch index in column 0 of coords / ori_coords, inds_reconstruct offset per view)."""
     coords, feats, inv, ori, xs, ys, imgs, caps = [], [], [], [], [], [], [], []
     base = 0
+    offsets = [0]
     for b, v in enumerate(views):
         vw = sd.views[v]
         pts = sd.points[vw["idx"]].contiguous()
+        offsets.append(offsets[-1] + pts.shape[0])
         grid, inds, inverse = voxelizer.voxelize_device(pts, None if matrices is None else matrices[b])
         coords.append(torch.cat([torch.full((grid.shape[0], 1), b, dtype=torch.int32, device=sd.device), grid], 1))
         feats.append((sd.colors[vw["idx"]][inds] / 127.5 - 1.0).float())
@@ -81,7 +83,7 @@ def build_scene_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, matrices=N
     coords = torch.cat(coords).contiguous()
     return {"sinput": ME.SparseTensor(torch.cat(feats).contiguous(), coords), "img": torch.cat(imgs), "x_label": torch.cat(xs),
             "y_label": torch.cat(ys), "inds_reconstruct": torch.cat(inv), "ori_coords": torch.cat(ori), "captions": tuple(caps),
-            "coords": coords, "label_2d": None, "labels_3d": None, "use_pure_3d": False}
+            "coords": coords, "label_2d": None, "labels_3d": None, "use_pure_3d": False, "point_offsets": offsets}
 
 
 def build_train_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, seed=0, n_classes=15, ignore=(19, 20)):
@@ -115,9 +117,9 @@ def build_train_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, seed=0, n_
             "binary_label_2d": None, "coords": coords}
 
 
-def nearest_index(query: torch.Tensor, ref: torch.Tensor):
-    """index into ref of the nearest reference point for every query point (exact; xm3d_nearest_index)"""
-    return ops.nearest_index(query.float().contiguous(), ref.float().contiguous())
+def nearest_index(query: torch.Tensor, ref: torch.Tensor, ref_valid=None):
+    """index into ref of the nearest (valid) reference point for every query point (exact; xm3d_nearest_index)"""
+    return ops.nearest_index(query.float().contiguous(), ref.float().contiguous(), ref_valid)
 
 
 def _gate(logits, binary_pred, base, novel):
@@ -128,12 +130,14 @@ def _gate(logits, binary_pred, base, novel):
 
 
 def postprocess_view(cfg, outputs, batch, with_ablations=True, s=0):
-    """-> class id per visible point of batch entry `s` for the fused / 2D-only / 3D-only predictions."""
+    """-> class id per visible point of batch entry `s` for the fused / 2D-only / 3D-only predictions.  Branch-free (no
+    host synchronisation): an empty mask set or a fully covered view simply selects nothing."""
     cs = cfg.category_split
     base, novel, allc = list(cs["base_category"]), list(cs["novel_category"]), list(cs["all_category"])
     text = F.normalize(outputs["text_embed"], dim=-1)
     scale = outputs["logit_scale"]
-    sel = batch["ori_coords"][:, 0] == s
+    offsets = batch.get("point_offsets")
+    sel = slice(offsets[s], offsets[s + 1]) if offsets is not None else (batch["ori_coords"][:, 0] == s)
     binary_pred = outputs["binary_pred"][sel]
     fused = F.normalize(outputs["fused_pred_feature"][s], dim=-1)
     probs = (scale * (fused @ text.t())).softmax(dim=-1)
@@ -141,9 +145,9 @@ def postprocess_view(cfg, outputs, batch, with_ablations=True, s=0):
     masks = outputs["final_mask_3d"][s]
     if masks.shape[0] > 0:
         open_p = (scale * (F.normalize(open_emb, dim=-1) @ text.t())).softmax(dim=-1)
-        overlap = torch.tensor([int(c in base) for c in allc], device=probs.device, dtype=probs.dtype)
+        overlap = torch.tensor([float(c in base) for c in allc], device=probs.device, dtype=probs.dtype)
         covered = masks.any(0)
-        q = masks.float().argmax(0)  # masks are pixel-disjoint: at most one per point
+        q = masks.to(torch.uint8).argmax(0)  # masks are pixel-disjoint: at most one per point
         po = open_p[q]
         b = (probs ** cfg.base_ratio * po ** (1 - cfg.base_ratio)).log() * overlap
         n = (probs ** cfg.novel_ratio * po ** (1 - cfg.novel_ratio)).log() * (1 - overlap)
@@ -151,12 +155,11 @@ def postprocess_view(cfg, outputs, batch, with_ablations=True, s=0):
     pred = _gate(probs, binary_pred, base, novel).argmax(1)
     if not with_ablations:
         return pred, None, None
-    f2d = outputs["2d_pred_feature"][s].clone()
+    f2d = outputs["2d_pred_feature"][s]
     empty = f2d.sum(1) == 0
-    if bool(empty.any()) and not bool(empty.all()):
-        xyz = batch["ori_coords"][sel][:, 1:]
-        src = torch.nonzero(~empty)[:, 0]
-        f2d[empty] = f2d[src[nearest_index(xyz[empty], xyz[src])]]
+    xyz = batch["ori_coords"][sel][:, 1:]
+    nn = nearest_index(xyz, xyz, ~empty)  # points without a 2D feature take the nearest covered point's (infer.py:523-553)
+    f2d = torch.where(empty[:, None], f2d[nn], f2d)
     pred2d = _gate(scale * (F.normalize(f2d, dim=-1) @ text.t()), binary_pred, base, novel).argmax(1)
     f3d = F.normalize(outputs["pure3d_pred_feature"][s], dim=-1)
     pred3d = _gate(scale * (f3d @ text.t()), binary_pred, base, novel).argmax(1)
@@ -178,6 +181,7 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
     for v0 in range(0, nv, step):
         views = list(range(v0, min(v0 + step, nv)))
         batch = build_scene_batch(sd, views, voxelizer, None if matrices is None else [matrices[v] for v in views])
+        batch["compact_outputs"] = False  # keep all Q mask rows (dropped ones all-False): no host sync in the fusion stage
         _, outputs = model(batch)
         for s, v in enumerate(views):
             preds = postprocess_view(cfg, outputs, batch, with_ablations, s)
@@ -186,15 +190,10 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
                 if p is not None:
                     vt.index_put_((idx, p), torch.ones_like(p, dtype=torch.int32), accumulate=True)
             seen[idx] = True
+    xyz = sd.points.float()
+    fill = nearest_index(xyz, xyz, seen)  # unseen points take the label of the nearest seen point (infer.py:682-694)
     out = []
-    fill = None
-    if not bool(seen.all()) and bool(seen.any()):
-        src = torch.nonzero(seen)[:, 0]
-        xyz = sd.points.float()
-        fill = src[nearest_index(xyz[~seen], xyz[src])]
     for vt in votes:
         p = vt.argmax(1)
-        if fill is not None:
-            p[~seen] = p[fill]
-        out.append(p)
+        out.append(torch.where(seen, p, p[fill]))
     return out

@@ -297,19 +297,26 @@ class XMASK3d(nn.Module):
         return losses, outputs
 
     def fuse_eval(self, outputs, batch_input, binary_scores):
+        """models/xmask3d.py:326-487 for every batch entry.  No host synchronisation when the batch carries
+        ``point_offsets`` (per-view point ranges) and ``compact_outputs`` is False: the reference's dynamic-size outputs
+        ``final_mask_3d`` (Qk,Np) / ``final_pred_open_embedding`` (Qk,768) are then returned over all Q queries with
+        all-False rows for the queries that were dropped (same votes downstream)."""
         cfg = self.cfg
         dev = outputs["pred_3d"].device
         masks = F.interpolate(outputs["pred_masks"], size=tuple(cfg.mask_shape), mode="bilinear", align_corners=False)
         ori_coords = batch_input["ori_coords"].to(dev)
         x_all, y_all = batch_input["x_label"].to(dev), batch_input["y_label"].to(dev)
         cs = cfg.category_split
-        base_cat = list(cs["base_category"] if isinstance(cs, dict) else cs.base_category)
-        novel_cat = list(cs["novel_category"] if isinstance(cs, dict) else cs.novel_category)
+        base_cat, novel_cat = list(cs["base_category"]), list(cs["novel_category"])
         num_classes = cfg.test_ignore_label[0]
+        offsets = batch_input.get("point_offsets")
+        compact = batch_input.get("compact_outputs", True)
+        n_scene = (len(offsets) - 1) if offsets is not None else int(ori_coords[:, 0].max().item()) + 1
+        Q = masks.shape[1]
+        qidx = torch.arange(Q, device=dev).view(-1, 1, 1)
         out, out2d, out3d, mask3d_l, open_l = [], [], [], [], []
-        n_scene = int(ori_coords[:, 0].max().item()) + 1
         for s in range(n_scene):
-            sel = ori_coords[:, 0] == s
+            sel = slice(offsets[s], offsets[s + 1]) if offsets is not None else (ori_coords[:, 0] == s)
             x_label, y_label = x_all[sel].contiguous(), y_all[sel].contiguous()
             p3d = outputs["pred_3d"][sel].contiguous()
             emb, emb_open = outputs["mask_embed"][s], outputs["mask_embed_clip"][s]
@@ -325,24 +332,20 @@ class XMASK3d(nn.Module):
             l_novel[:, base_cat + [num_classes]] = -1e10
             l_base[:, novel_cat] = -1e10
             modified = is_base * l_base + (~is_base) * l_novel
-            scores, labels = F.softmax(modified, dim=-1).max(-1)
+            scores = F.softmax(modified, dim=-1).max(-1)[0]
             mask_pred = m.sigmoid()
             keep = keep_full & (scores > cfg.scores_keep_thresh)
             # queries not kept must not win the per-pixel arg-max: give them score -1 (kept scores are > 0)
             prob = torch.where(keep, scores, torch.full_like(scores, -1.0)).view(-1, 1, 1) * mask_pred
-            if bool(keep.any()):
-                ids = prob.argmax(0)
-                q = torch.arange(m.shape[0], device=dev).view(-1, 1, 1)
-                final = (ids[None] == q) & (mask_pred >= 0.5) & keep.view(-1, 1, 1)
+            ids = prob.argmax(0)
+            final = (ids[None] == qidx) & (mask_pred >= 0.5) & keep.view(-1, 1, 1)  # all False when nothing is kept
+            feat2d, cnt = ops.mask_point_fuse(final.to(torch.uint8).contiguous(), x_label, y_label, emb.float().contiguous())
+            mask_3d = final[:, x_label, y_label]
+            if compact:
                 final_keep = final.flatten(1).any(1)
-                feat2d, cnt = ops.mask_point_fuse(final.to(torch.uint8).contiguous(), x_label, y_label, emb.float().contiguous())
-                mask_3d = final[final_keep][:, x_label, y_label]
-                open_sel = emb_open[final_keep]
+                mask_3d, open_sel = mask_3d[final_keep], emb_open[final_keep]
             else:
-                feat2d = torch.zeros_like(p3d)
-                cnt = torch.zeros(p3d.shape[0], dtype=torch.int32, device=dev)
-                mask_3d = torch.zeros((0, p3d.shape[0]), dtype=torch.bool, device=dev)
-                open_sel = emb_open[:0]
+                open_sel = emb_open
             need = (cnt >= 1).view(-1, 1)
             fused = torch.where(need, self.criterion.fuser(feat2d, p3d), p3d)
             out.append(fused)
