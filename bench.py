@@ -113,13 +113,20 @@ def main():
             raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a ROCm device (there is no CPU fallback for the product path)")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    backend = os.environ.get("XM3D_DIST_BACKEND", "nccl")  # "gloo" only to rehearse N>1 on a box with fewer GPUs than ranks
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and backend == "nccl":
+        raise SystemExit(f"LOCAL_RANK {local_rank} but only {ndev} GPUs visible")
+    torch.cuda.set_device(local_rank % ndev)
+    dev = torch.device("cuda", local_rank % ndev)
     import torch.distributed as dist
 
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
 
     if args.roofline_only:
         print(json.dumps({"roofline": spconv_roofline(dev)}))
@@ -177,8 +184,11 @@ def main():
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     _ops.fnv_keys(marker)
+    ok = all(bool(torch.isfinite(p.float()).all()) and int(p.min()) >= 0 and int(p.max()) < cfg.test_classes for p in preds)
+    if not ok:
+        raise SystemExit("bench: scene predictions are not finite class ids - refusing to report a number")
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     if rank != 0:
