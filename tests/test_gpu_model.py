@@ -135,3 +135,18 @@ def test_batched_views_equal_single_view_forwards(dev, models):
             assert out["fused_pred_feature"][s].shape == ref["fused_pred_feature"][0].shape
             if out["final_mask_3d"][s].shape == ref["final_mask_3d"][0].shape and bool((out["final_mask_3d"][s] == ref["final_mask_3d"][0]).all()):
                 assert _rel(out["fused_pred_feature"][s], ref["fused_pred_feature"][0]) < 5e-3
+
+
+def test_cross_scene_prefetch_does_not_change_results(dev, models):
+    from xmask3d_amd import pipeline, synthetic
+
+    cfg, _, gpu = models
+    g = copy.deepcopy(gpu).enable_dense_graph()
+    sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
+    T = [np.diag([50.0, 50.0, 50.0, 1.0])] * 5
+    vox = pipeline.default_voxelizer(device=dev)
+    a = pipeline.infer_scene(g, sd, cfg, vox, T)                       # no prefetch
+    b = pipeline.infer_scene(g, sd, cfg, vox, T, next_scene=sd)        # prefetches for the next call
+    c = pipeline.infer_scene(g, sd, cfg, vox, T)                       # consumes the prefetched encoder output
+    for x, y, z in zip(a, b, c):
+        assert (x == y).float().mean().item() > 0.995 and (x == z).float().mean().item() > 0.995

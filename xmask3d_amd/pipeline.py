@@ -48,6 +48,7 @@ class SceneOnDevice:
                 x=torch.from_numpy(rows).long().to(device), y=torch.from_numpy(cols).long().to(device),
                 img=torch.from_numpy(scene.images[v]).permute(2, 0, 1)[None].contiguous().to(device),
                 caption=scene.captions[v]))
+        self.img_all = torch.cat([v["img"] for v in self.views])  # all views as one batch (stable storage: prefetch key)
 
 
 def build_view_batch(sd: SceneOnDevice, view: int, voxelizer: Voxelizer, matrix=None):
@@ -81,7 +82,8 @@ def build_scene_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, matrices=N
         ori.append(torch.cat([torch.full((pts.shape[0], 1), float(b), device=sd.device), pts.float()], 1))
         xs.append(vw["x"]); ys.append(vw["y"]); imgs.append(vw["img"]); caps.append(vw["caption"])
     coords = torch.cat(coords).contiguous()
-    return {"sinput": ME.SparseTensor(torch.cat(feats).contiguous(), coords), "img": torch.cat(imgs), "x_label": torch.cat(xs),
+    img = sd.img_all if list(views) == list(range(len(sd.views))) else torch.cat(imgs)
+    return {"sinput": ME.SparseTensor(torch.cat(feats).contiguous(), coords), "img": img, "x_label": torch.cat(xs),
             "y_label": torch.cat(ys), "inds_reconstruct": torch.cat(inv), "ori_coords": torch.cat(ori), "captions": tuple(caps),
             "coords": coords, "label_2d": None, "labels_3d": None, "use_pure_3d": False, "point_offsets": offsets}
 
@@ -167,11 +169,14 @@ def postprocess_view(cfg, outputs, batch, with_ablations=True, s=0):
 
 
 @torch.no_grad()
-def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, with_ablations=True, views_per_batch=None):
+def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, with_ablations=True, views_per_batch=None,
+                next_scene: SceneOnDevice | None = None):
     """All views of one scene -> per-point class votes -> arg-max, unseen points take the nearest seen point's label.
     views_per_batch: how many views go through the model together (default: all of them, one forward per scene; 1 =
     the reference's batch-1 loop, run/infer.py:428-482).  Per-view results do not depend on the grouping.
-    matrices: optional list of 4x4 voxelisation transforms (otherwise drawn from np.random like the reference)."""
+    matrices: optional list of 4x4 voxelisation transforms (otherwise drawn from np.random like the reference).
+    next_scene: the scene that will be inferred next; its VAE-encoder graph is enqueued on the side stream as soon as this
+    scene's dense graphs are in flight, so it overlaps this scene's post-processing (software pipelining across scenes)."""
     voxelizer = voxelizer or default_voxelizer(cfg.voxel_size, sd.device)
     ncls = len(cfg.category_split["base_category"]) + len(cfg.category_split["novel_category"])
     votes = [torch.zeros((sd.n, ncls), dtype=torch.int32, device=sd.device) for _ in range(3 if with_ablations else 1)]
@@ -183,6 +188,8 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
         batch = build_scene_batch(sd, views, voxelizer, None if matrices is None else [matrices[v] for v in views])
         batch["compact_outputs"] = False  # keep all Q mask rows (dropped ones all-False): no host sync in the fusion stage
         _, outputs = model(batch)
+        if next_scene is not None and v0 + step >= nv and step >= nv and hasattr(model, "prefetch_encoder"):
+            model.prefetch_encoder(next_scene.img_all)
         for s, v in enumerate(views):
             preds = postprocess_view(cfg, outputs, batch, with_ablations, s)
             idx = sd.views[v]["idx"]
