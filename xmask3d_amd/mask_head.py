@@ -340,6 +340,9 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
         self.class_embed = class_embed if class_embed is not None else nn.Linear(hidden_dim, num_classes + 1)
         self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
         self.post_mask_embed = post_mask_embed
+        # eval only: the pooled mask-CLIP embedding of the 9 intermediate layers feeds nothing but the training losses;
+        # the reference computes it anyway (odise.py:445-491).  True = skip it outside training (like SURVEY F7).
+        self.prune_aux_embed = False
 
     def forward(self, x, mask_features, mask=None):
         assert len(x) == self.num_feature_levels
@@ -352,7 +355,8 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
         query_embed = self.query_embed.weight.unsqueeze(1).repeat(1, bs, 1)
         output = self.query_feat.weight.unsqueeze(1).repeat(1, bs, 1)
         cls_l, mask_l, extra_l = [], [], []
-        c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[0])
+        skip = self.prune_aux_embed and not self.training
+        c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[0], not skip)
         cls_l.append(c), mask_l.append(m), extra_l.append(e)
         for i in range(self.num_layers):
             lvl = i % self.num_feature_levels
@@ -363,23 +367,25 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
                                                                 query_pos=query_embed)
             output = self.transformer_self_attention_layers[i](output, query_pos=query_embed)
             output = self.transformer_ffn_layers[i](output)
-            c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[(i + 1) % self.num_feature_levels])
+            c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[(i + 1) % self.num_feature_levels],
+                                                               not skip or i == self.num_layers - 1)
             cls_l.append(c), mask_l.append(m), extra_l.append(e)
         out = {"pred_logits": cls_l[-1], "pred_masks": mask_l[-1],
                "aux_outputs": [{"pred_logits": a, "pred_masks": b} for a, b in zip(cls_l[:-1], mask_l[:-1])]}
         for k in extra_l[-1]:
             out[k] = extra_l[-1][k]
             for i in range(len(extra_l) - 1):
-                out["aux_outputs"][i][k] = extra_l[i][k]
+                if k in extra_l[i]:
+                    out["aux_outputs"][i][k] = extra_l[i][k]
         return out
 
-    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size):
+    def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, with_embed=True):
         decoder_output = self.decoder_norm(output).transpose(0, 1)
         outputs_class = self.class_embed(decoder_output)
         mask_embed = self.mask_embed(decoder_output)
         outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
         extra = {}
-        if self.post_mask_embed is not None:
+        if self.post_mask_embed is not None and with_embed:
             extra.update(self.post_mask_embed(decoder_output, mask_embed, mask_features, outputs_class, outputs_mask))
         attn_mask = F.interpolate(outputs_mask, size=attn_mask_target_size, mode="bilinear", align_corners=False)
         attn_mask = (attn_mask.sigmoid().flatten(2).unsqueeze(1).repeat(1, self.num_heads, 1, 1).flatten(0, 1) < 0.5).bool()

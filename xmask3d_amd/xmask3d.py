@@ -86,6 +86,7 @@ class XMASK3d(nn.Module):
                 mask_classification=True, num_classes=num_classes, num_queries=num_queries, nheads=8, dim_feedforward=2048,
                 dec_layers=9, pre_norm=False, enforce_input_project=False, mask_dim=256),
             input_shape=self.backbone.output_shape())
+        self.sem_seg_head.predictor.prune_aux_embed = prune_dead_compute
         self.criterion = Criterion(
             num_layers=9, class_weight=2.0, mask_weight=5.0, dice_weight=5.0, num_classes=num_classes,
             matcher=HungarianMatcher(cost_class=2.0, cost_mask=5.0, cost_dice=5.0, num_points=12544), eos_coef=0.1,
