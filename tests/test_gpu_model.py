@@ -150,3 +150,27 @@ def test_cross_scene_prefetch_does_not_change_results(dev, models):
     c = pipeline.infer_scene(g, sd, cfg, vox, T)                       # consumes the prefetched encoder output
     for x, y, z in zip(a, b, c):
         assert (x == y).float().mean().item() > 0.995 and (x == z).float().mean().item() > 0.995
+
+
+@pytest.mark.parametrize("name,n_train,n_test", [("xmask3d_scannet_B12N7", 12, 19), ("xmask3d_scannet_B170N30", 170, 200)])
+def test_other_benchmark_configs_run(dev, name, n_train, n_test):
+    """BASELINE.json configs 4 and 5: novel-class stress (12 base / 7 novel) and the 200-class head (170/30, Q stays 50)."""
+    from xmask3d_amd import pipeline, synthetic
+    from xmask3d_amd.config import load_cfg_from_cfg_file
+    from xmask3d_amd.xmask3d import XMASK3d
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_cfg_from_cfg_file(os.path.join(root, "configs", name + ".yaml"))
+    assert cfg.classes == n_train and cfg.test_classes == n_test and cfg.num_queries == 50
+    torch.manual_seed(1)
+    with torch.device(dev):  # parameters are created (and randomly initialised) directly in HBM
+        model = XMASK3d(cfg, dense_dtype=torch.bfloat16).eval()
+    model = model.to(dev)
+    sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
+    np.random.seed(3)
+    with torch.no_grad():
+        _, out = model(pipeline.build_scene_batch(sd, [0, 1], pipeline.default_voxelizer(device=dev)))
+        assert out["pred_logits"].shape == (2, 50, n_test + 1) and out["text_embed"].shape == (n_test, 768)
+        preds = pipeline.infer_scene(model, sd, cfg, views_per_batch=5)
+    assert all(int(p.max()) < n_test and int(p.min()) >= 0 for p in preds)

@@ -26,11 +26,16 @@ from .xmask3d import XMASK3d
 
 def setup_distributed(cfg):
     rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
+    ndev = torch.cuda.device_count()
+    backend = os.environ.get("XM3D_DIST_BACKEND", cfg.dist_backend)  # "gloo": rehearse N ranks on fewer GPUs
+    torch.cuda.set_device(local % ndev)
+    dev = torch.device("cuda", local % ndev)
     if world > 1 and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend=cfg.dist_backend, device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend=backend)
     return rank, world, dev
 
 

@@ -42,7 +42,7 @@ class LatentDiffusion(nn.Module):
         self.unet_model = UNetModel()
         self.image_size, self.latent_image_size, self.latent_dim = (512, 512), (64, 64), 4
         g = torch.Generator().manual_seed(0)
-        self.register_buffer("uncond_inputs", torch.randn(1, 77, 768, generator=g) * 0.5)
+        self.register_buffer("uncond_inputs", torch.randn(1, 77, 768, generator=g, device="cpu") * 0.5)
         self.register_buffer("pixel_mean", torch.tensor([0.5, 0.5, 0.5]).view(-1, 1, 1), False)
         self.register_buffer("pixel_std", torch.tensor([0.5, 0.5, 0.5]).view(-1, 1, 1), False)
 
@@ -69,7 +69,7 @@ class LdmExtractor(nn.Module):
         self.prune_dead_compute = prune_dead_compute
         self.ldm = LatentDiffusion()
         rng = torch.Generator().manual_seed(42)
-        self.register_buffer("shared_noise", torch.randn(1, 4, 64, 64, generator=rng))
+        self.register_buffer("shared_noise", torch.randn(1, 4, 64, 64, generator=rng, device="cpu"))
         for p in self.parameters():
             p.requires_grad = False
 
