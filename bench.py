@@ -94,7 +94,7 @@ def spconv_roofline(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="dtype of the frozen dense nets (SD, CLIP)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -225,7 +225,7 @@ def main():
                 "hip_kernel": roof_kernel}
 
     cpu_baseline = None
-    if not args.no_cpu_baseline:
+    if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
         from oracle import model_oracle, voxel_oracle
 
         log("cpu baseline (1 view through the oracle)")

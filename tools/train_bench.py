@@ -11,6 +11,7 @@ from xmask3d_amd.xmask3d import XMASK3d
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+dtype = torch.bfloat16 if (len(sys.argv) > 3 and sys.argv[3] == "bf16") else torch.float32
 rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
@@ -18,7 +19,7 @@ if world > 1:
     dist.init_process_group("nccl", device_id=dev)
 cfg = load_cfg_from_cfg_file(os.path.join(ROOT, "configs", "xmask3d_scannet_B15N4.yaml"))
 torch.manual_seed(cfg.manual_seed)
-model = XMASK3d(cfg).to(dev).train()
+model = XMASK3d(cfg).to(dev).set_dense_dtype(dtype).train()
 if world > 1:
     ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)      # per-GPU batch < 4 (run/train.py:185-187)
     model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
@@ -38,7 +39,7 @@ def it(i):
     opt.zero_grad(set_to_none=True)
     loss.backward()
     opt.step()
-    return float(loss)
+    return float(loss.detach())
 
 for i in range(2):
     l = it(i)
@@ -51,6 +52,6 @@ torch.cuda.synchronize()
 if world > 1: dist.barrier()
 dt = (time.perf_counter() - t) / iters
 if rank == 0:
-    print(f"train: world {world} x {B} views/GPU: {dt*1e3:.1f} ms/iter = {1/dt:.2f} iters/s ({world*B/dt:.2f} views/s), last loss {l:.3f}, "
+    print(f"train[{'bf16' if dtype == torch.bfloat16 else 'fp32'} frozen nets]: world {world} x {B} views/GPU: {dt*1e3:.1f} ms/iter = {1/dt:.2f} iters/s ({world*B/dt:.2f} views/s), last loss {l:.3f}, "
           f"max mem {torch.cuda.max_memory_allocated()/2**30:.1f} GiB", flush=True)
 if world > 1: dist.destroy_process_group()
