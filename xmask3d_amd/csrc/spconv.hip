@@ -233,7 +233,7 @@ struct __attribute__((aligned(16))) TileLds {
 };
 
 // Per-wave software pipeline over the wave's own tile sequence (which spans steps):
-//   stage A: pair indices (tsrc/tdst) of tile i+2      stage B: row gathers of tile i+1      stage C: MFMAs of tile i
+//   stage A: pair indices (tsrc/tdst) of tile i+3      stage B: row gathers of tile i+2      stage C: MFMAs of tile i
 // so the count -> index -> gather chain of dependent L2 round trips is off the critical path.
 template <int ST_>
 __global__ __launch_bounds__(256, 2) void k_spconv_tiles(const float* __restrict__ in, int cin, const float* __restrict__ Wp,
@@ -317,22 +317,26 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tiles(const float* __restrict
         }
     };
 
+    // pipeline registers: indices three tiles ahead (s3,d3), gathers two tiles ahead (x2), MFMAs on x0
     Ref r0 = advance(Ref{0, wave - WAVES});
     Ref r1 = advance(r0);
-    int s0, d0, s1, d1;
+    Ref r2 = advance(r1);
+    int s0, d0, s1, d1, s2, d2;
     load_idx(r0, s0, d0);
     load_idx(r1, s1, d1);
-    f32x4 x0[ST_], x1[ST_];
+    load_idx(r2, s2, d2);
+    f32x4 x0[ST_], x1[ST_], x2[ST_];
     gather(r0, s0, x0);
+    gather(r1, s1, x1);
 
     int cur = 0;
     for (int step = 0; step < nsteps; ++step) {
         if (step + 1 < nsteps) load_w(step + 1);
         while (r0.step == step) {
-            const Ref r2 = advance(r1);
-            int s2, d2;
-            load_idx(r2, s2, d2);   // stage A for tile i+2
-            gather(r1, s1, x1);     // stage B for tile i+1
+            const Ref r3 = advance(r2);
+            int s3, d3;
+            load_idx(r3, s3, d3);   // stage A for tile i+3
+            gather(r2, s2, x2);     // stage B for tile i+2
 #pragma unroll
             for (int n = 0; n < NT; ++n) {  // stage C
                 f32x4 d = {0.f, 0.f, 0.f, 0.f};
@@ -352,12 +356,17 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tiles(const float* __restrict
                 }
             }
 #pragma unroll
-            for (int s = 0; s < ST_; ++s) x0[s] = x1[s];
+            for (int s = 0; s < ST_; ++s) {
+                x0[s] = x1[s];
+                x1[s] = x2[s];
+            }
             d0 = d1;
-            s1 = s2;
             d1 = d2;
+            s2 = s3;
+            d2 = d3;
             r0 = r1;
             r1 = r2;
+            r2 = r3;
         }
         if (step + 1 < nsteps) store_w(cur ^ 1);
         __syncthreads();
