@@ -99,6 +99,7 @@ def main():
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="dtype of the frozen dense nets (SD, CLIP)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views-per-batch", type=int, default=0, help="views per forward (0 = all views of the scene; 1 = reference loop)")
+    ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find through the shipped find-db)")
     ap.add_argument("--no-graph", action="store_true", help="launch the dense branch eagerly instead of replaying a HIP graph")
     ap.add_argument("--faithful-dead-compute", action="store_true", help="also run what the reference computes and discards")
     ap.add_argument("--roofline-only", action="store_true",
@@ -139,8 +140,12 @@ def main():
     if world > 1:
         dist.barrier()
 
-    from xmask3d_amd import pipeline, synthetic
+    from xmask3d_amd import pipeline, synthetic  # noqa: E402  (sets MIOPEN_USER_DB_PATH before the first convolution)
     from xmask3d_amd.config import load_cfg_from_cfg_file
+
+    if args.miopen_find:
+        torch.backends.cudnn.benchmark = True
+    log(f"MIOPEN_USER_DB_PATH={os.environ.get('MIOPEN_USER_DB_PATH')} cudnn.benchmark={torch.backends.cudnn.benchmark}")
     from xmask3d_amd.xmask3d import XMASK3d
 
     cfg = load_cfg_from_cfg_file(os.path.join(ROOT, "configs", "xmask3d_scannet_B15N4.yaml"))
