@@ -183,11 +183,13 @@ int xm3d_mask_point_fuse(const uint8_t* masks, int32_t Q, int32_t Hm, int32_t Wm
 /* ---------------------------------------------------------------------------
  * Exact 1-nearest-neighbour index (replaces sklearn.neighbors.KDTree(...).query(k=1) in run/infer.py:523-553,
  * :682-694): query (n,3) f32, ref (m,3) f32, out (n) i64 = arg-min squared distance, lowest index on ties.
- * ref_valid (m) u8 or NULL: reference points with 0 are ignored (replaces compacting the reference set on the host;
- * if no reference point is valid the result is index 0).
+ * ref_valid (m) u8 or NULL: reference points with 0 are ignored (if no reference point is valid the result is 0).
+ * counts (2) i64 DEVICE or NULL: {live queries, live references}: only the first counts[0] rows of query and the first
+ * counts[1] rows of ref take part (out rows beyond counts[0] are left untouched) - lets the caller order "live" rows
+ * first on the device and skip the rest without reading a count back to the host.
  * ------------------------------------------------------------------------- */
 int xm3d_nearest_index(const float* query, int64_t n, const float* ref, int64_t m, const uint8_t* ref_valid,
-                       int64_t* out, void* stream);
+                       const int64_t* counts, int64_t* out, void* stream);
 
 #ifdef __cplusplus
 }

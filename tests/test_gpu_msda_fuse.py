@@ -143,3 +143,22 @@ def test_nearest_index_is_exact(dev):
     dm = d.clone()
     dm[:, ~valid] = float("inf")
     assert valid[got].all() and (dm.gather(1, got[:, None])[:, 0] <= dm.min(1).values + 1e-9).all()
+
+
+def test_nearest_valid_fill_matches_bruteforce(dev):
+    from xmask3d_amd import pipeline
+
+    torch.manual_seed(1)
+    xyz = torch.rand(7000, 3) * 3
+    valid = torch.rand(7000) < 0.35
+    fill = pipeline.nearest_valid_fill(xyz.to(dev), valid.to(dev)).cpu()
+    d = torch.cdist(xyz.double(), xyz[valid].double())
+    src = torch.nonzero(valid)[:, 0]
+    want = src[d.argmin(1)]
+    assert (fill[valid] == torch.nonzero(valid)[:, 0]).all()
+    got_d = (xyz[~valid].double() - xyz[fill[~valid]].double()).norm(dim=1)
+    assert valid[fill].all() and torch.allclose(got_d, d[~valid].min(1).values, atol=1e-6)
+    # degenerate masks: everything valid -> identity; nothing valid -> every index is a legal row
+    assert (pipeline.nearest_valid_fill(xyz.to(dev), torch.ones(7000, dtype=torch.bool, device=dev)).cpu() == torch.arange(7000)).all()
+    none = pipeline.nearest_valid_fill(xyz.to(dev), torch.zeros(7000, dtype=torch.bool, device=dev)).cpu()
+    assert int(none.min()) >= 0 and int(none.max()) < 7000

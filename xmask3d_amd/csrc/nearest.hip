@@ -10,8 +10,14 @@ namespace xm3d {
 constexpr int NN_TILE = 1024;
 
 __global__ __launch_bounds__(256) void k_nearest(const float* __restrict__ q, int64_t n, const float* __restrict__ r, int64_t m,
-                                                 const uint8_t* __restrict__ valid, int64_t* __restrict__ out) {
+                                                 const uint8_t* __restrict__ valid, const int64_t* __restrict__ counts,
+                                                 int64_t* __restrict__ out) {
     __shared__ float4 tile[NN_TILE];
+    if (counts) {  // device-resident sizes: only the first counts[0] queries / counts[1] references take part
+        n = counts[0] < n ? counts[0] : n;
+        m = counts[1] < m ? counts[1] : m;
+        if (int64_t(blockIdx.x) * blockDim.x >= n) return;  // whole workgroup beyond the live queries
+    }
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     float qx = 0.f, qy = 0.f, qz = 0.f;
     if (i < n) {
@@ -55,11 +61,11 @@ __global__ __launch_bounds__(256) void k_nearest(const float* __restrict__ q, in
 using namespace xm3d;
 
 extern "C" int xm3d_nearest_index(const float* query, int64_t n, const float* ref, int64_t m, const uint8_t* ref_valid,
-                                  int64_t* out, void* stream) {
+                                  const int64_t* counts, int64_t* out, void* stream) {
     XM3D_REQUIRE(n >= 0 && m >= 1, "nearest_index: need n >= 0 queries and m >= 1 reference points (n=%lld m=%lld)", (long long)n, (long long)m);
     if (n == 0) return XM3D_OK;
     XM3D_REQUIRE(query && ref && out, "nearest_index: null pointer");
-    hipLaunchKernelGGL(k_nearest, dim3(unsigned((n + 255) / 256)), dim3(256), 0, as_stream(stream), query, n, ref, m, ref_valid, out);
+    hipLaunchKernelGGL(k_nearest, dim3(unsigned((n + 255) / 256)), dim3(256), 0, as_stream(stream), query, n, ref, m, ref_valid, counts, out);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }

@@ -362,9 +362,10 @@ def mask_point_fuse(masks_u8, x_label, y_label, embed):
 
 
 # ---------------------------------------------------------------- nearest neighbour
-def nearest_index(query, ref, ref_valid=None):
+def nearest_index(query, ref, ref_valid=None, counts=None):
     """(n,3) f32, (m,3) f32 -> (n,) i64 index of the nearest reference point (exact, lowest index on ties).
-    ref_valid (m,) uint8/bool: only reference points with a non-zero flag are considered."""
+    ref_valid (m,) uint8/bool: only reference points with a non-zero flag are considered.
+    counts (2,) i64 device tensor {live queries, live refs}: only those leading rows take part (others: out = 0)."""
     _req(query, torch.float32, "query", 2)
     _req(ref, torch.float32, "ref", 2)
     if ref_valid is not None:
@@ -374,7 +375,12 @@ def nearest_index(query, ref, ref_valid=None):
         assert ref_valid.numel() == ref.shape[0]
     if query.shape[1] != 3 or ref.shape[1] != 3:
         raise RuntimeError("nearest_index works on 3-D points")
-    out = torch.empty(query.shape[0], dtype=torch.int64, device=query.device)
-    check(lib().xm3d_nearest_index(_ptr(query), query.shape[0], _ptr(ref), ref.shape[0], _ptr(ref_valid), _ptr(out), _stream()),
-          "xm3d_nearest_index")
+    if counts is not None:
+        _req(counts, torch.int64, "counts", 1)
+        assert counts.numel() == 2
+        out = torch.zeros(query.shape[0], dtype=torch.int64, device=query.device)
+    else:
+        out = torch.empty(query.shape[0], dtype=torch.int64, device=query.device)
+    check(lib().xm3d_nearest_index(_ptr(query), query.shape[0], _ptr(ref), ref.shape[0], _ptr(ref_valid), _ptr(counts), _ptr(out),
+                                   _stream()), "xm3d_nearest_index")
     return out

@@ -124,6 +124,23 @@ def nearest_index(query: torch.Tensor, ref: torch.Tensor, ref_valid=None):
     return ops.nearest_index(query.float().contiguous(), ref.float().contiguous(), ref_valid)
 
 
+def nearest_valid_fill(xyz: torch.Tensor, valid: torch.Tensor):
+    """For every point: its own index if `valid`, else the index of the nearest valid point.  No host synchronisation and
+    no wasted scanning: rows are ordered on the device (queries: invalid first, references: valid first) and the live
+    counts stay in device memory (xm3d_nearest_index `counts`)."""
+    n = xyz.shape[0]
+    xyz = xyz.float()
+    q_order = torch.argsort(valid.to(torch.uint8), stable=True)          # invalid points first = the queries
+    r_order = torch.argsort((~valid).to(torch.uint8), stable=True)       # valid points first = the references
+    n_valid = valid.sum()
+    counts = torch.stack([n - n_valid, n_valid]).to(torch.int64)
+    nn = ops.nearest_index(xyz[q_order].contiguous(), xyz[r_order].contiguous(), None, counts)
+    fill = torch.arange(n, device=xyz.device)
+    live = torch.arange(n, device=xyz.device) < (n - n_valid)
+    # scatter the answers of the live queries back; every other point keeps its own index
+    return fill.scatter(0, q_order, torch.where(live, r_order[nn], q_order))
+
+
 def _gate(logits, binary_pred, base, novel):
     lb, ln = logits.clone(), logits.clone()
     ln[:, base] = -1e10
@@ -160,8 +177,7 @@ def postprocess_view(cfg, outputs, batch, with_ablations=True, s=0):
     f2d = outputs["2d_pred_feature"][s]
     empty = f2d.sum(1) == 0
     xyz = batch["ori_coords"][sel][:, 1:]
-    nn = nearest_index(xyz, xyz, ~empty)  # points without a 2D feature take the nearest covered point's (infer.py:523-553)
-    f2d = torch.where(empty[:, None], f2d[nn], f2d)
+    f2d = f2d[nearest_valid_fill(xyz, ~empty)]  # points without a 2D feature take the nearest covered point's (infer.py:523-553)
     pred2d = _gate(scale * (F.normalize(f2d, dim=-1) @ text.t()), binary_pred, base, novel).argmax(1)
     f3d = F.normalize(outputs["pure3d_pred_feature"][s], dim=-1)
     pred3d = _gate(scale * (f3d @ text.t()), binary_pred, base, novel).argmax(1)
@@ -197,10 +213,5 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
                 if p is not None:
                     vt.index_put_((idx, p), torch.ones_like(p, dtype=torch.int32), accumulate=True)
             seen[idx] = True
-    xyz = sd.points.float()
-    fill = nearest_index(xyz, xyz, seen)  # unseen points take the label of the nearest seen point (infer.py:682-694)
-    out = []
-    for vt in votes:
-        p = vt.argmax(1)
-        out.append(torch.where(seen, p, p[fill]))
-    return out
+    fill = nearest_valid_fill(sd.points, seen)  # unseen points take the label of the nearest seen point (infer.py:682-694)
+    return [vt.argmax(1)[fill] for vt in votes]
