@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views-per-batch", type=int, default=0, help="views per forward (0 = all views of the scene; 1 = reference loop)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find through the shipped find-db)")
+    ap.add_argument("--channels-last", action="store_true", help="NHWC activations in the frozen conv nets")
     ap.add_argument("--no-graph", action="store_true", help="launch the dense branch eagerly instead of replaying a HIP graph")
     ap.add_argument("--faithful-dead-compute", action="store_true", help="also run what the reference computes and discards")
     ap.add_argument("--roofline-only", action="store_true",
@@ -156,6 +157,8 @@ def main():
     model = copy.deepcopy(cpu_model).to(dev).eval()
     dense_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.set_dense_dtype(dense_dtype)
+    if args.channels_last:
+        model.set_channels_last(True)
     if not args.no_graph:
         model.enable_dense_graph()
 

@@ -148,6 +148,9 @@ int xm3d_affine_act(const float* x, int64_t n, int32_t c, const float* scale, co
  * ------------------------------------------------------------------------- */
 int xm3d_group_norm(const void* x, int32_t dtype, int64_t B, int32_t C, int32_t hw, int32_t G, const void* gamma,
                     const void* beta, float eps, int32_t silu, void* y, double* stats_ws, void* stream);
+/* Same for channels-last activations: x, y are (B, H*W, C) contiguous (NHWC); C a multiple of 4 (f32) / 8 (bf16), G <= 64. */
+int xm3d_group_norm_nhwc(const void* x, int32_t dtype, int64_t B, int32_t C, int32_t hw, int32_t G, const void* gamma,
+                         const void* beta, float eps, int32_t silu, void* y, double* stats_ws, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Multi-scale deformable attention (replaces the pybind module

@@ -120,6 +120,11 @@ def test_fused_group_norm_matches_torch(dev, dtype, shape, act):
     assert y.dtype == dtype and y.shape == x.shape
     tol = 1e-5 if dtype == torch.float32 else 2e-2  # bf16 output rounding
     assert (y.float().cpu() - ref).abs().max().item() <= tol * max(ref.abs().max().item(), 1.0)
+    # channels-last input -> NHWC kernel, channels-last output, same values
+    xc = x.to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    yc = ops.group_norm(xc, 32, w.to(dev).to(dtype), b.to(dev).to(dtype), 1e-6, act)
+    assert yc.is_contiguous(memory_format=torch.channels_last) and yc.shape == x.shape
+    assert (yc.float().cpu() - ref).abs().max().item() <= max(tol, 2e-5) * max(ref.abs().max().item(), 1.0)
 
 
 def test_nearest_index_is_exact(dev):

@@ -15,6 +15,9 @@ torch.manual_seed(0)
 with torch.device(dev):
     model = XMASK3d(cfg, dense_dtype=torch.bfloat16).eval()
 model = model.to(dev)
+if os.environ.get('XM3D_CL') == '1':
+    model.set_channels_last(True)
+    print('channels_last on', flush=True)
 sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
 vox = pipeline.default_voxelizer(device=dev)
 T = np.diag([50.0, 50.0, 50.0, 1.0])

@@ -126,6 +126,125 @@ __global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x, const
     }
 }
 
+// ---------------------------------------------------------------- NHWC (channels-last) variants
+// x is (B, HW, C): a pixel's C channels are contiguous, so a 16-byte vector holds N consecutive channels of one pixel.
+// Statistics: a workgroup owns a slab of pixels of one sample; thread t owns vector column (t % VPP) and walks pixels with
+// stride (256 / VPP); per-element f32 partials are folded per group into LDS (f32 atomics), then one f64 atomic pair per
+// (workgroup, group).  Apply: per element group lookup (a vector may straddle two groups when C/G < N).
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_stats_nhwc(const T* __restrict__ x, int hw, int C, int cg, int G, int slabs, int pix,
+                                                       double* __restrict__ stats) {
+    constexpr int N = VecIO<T>::N;
+    __shared__ float sm[2 * 64];  // G <= 64
+    const int b = blockIdx.x / slabs, slab = blockIdx.x % slabs;
+    if (threadIdx.x < 2 * G) sm[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int vpp = C / N;                         // vectors per pixel
+    const int p0 = slab * pix;
+    const int p1 = (p0 + pix < hw) ? p0 + pix : hw;
+    const T* base = x + int64_t(b) * hw * C;
+    for (int v = threadIdx.x % (vpp < 256 ? vpp : 256); v < vpp; v += 256) {  // vpp > 256 only for C > 2048 (bf16)
+        const int lanes = vpp < 256 ? 256 / vpp : 1;  // pixel lanes sharing this vector column
+        const int pl = vpp < 256 ? threadIdx.x / vpp : 0;
+        if (pl >= lanes) continue;
+        float s[N], ss[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) s[j] = ss[j] = 0.f;
+        for (int p = p0 + pl; p < p1; p += lanes) {
+            float val[N];
+            VecIO<T>::load(base + int64_t(p) * C + v * N, val);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                s[j] += val[j];
+                ss[j] = fmaf(val[j], val[j], ss[j]);
+            }
+        }
+        int gprev = (v * N) / cg;
+        float as = 0.f, ass = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int g = (v * N + j) / cg;
+            if (g != gprev) {
+                atomicAdd(&sm[2 * gprev], as);
+                atomicAdd(&sm[2 * gprev + 1], ass);
+                as = ass = 0.f;
+                gprev = g;
+            }
+            as += s[j];
+            ass += ss[j];
+        }
+        atomicAdd(&sm[2 * gprev], as);
+        atomicAdd(&sm[2 * gprev + 1], ass);
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        atomicAdd(&stats[(int64_t(b) * G + threadIdx.x) * 2], double(sm[2 * threadIdx.x]));
+        atomicAdd(&stats[(int64_t(b) * G + threadIdx.x) * 2 + 1], double(sm[2 * threadIdx.x + 1]));
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_gn_apply_nhwc(const T* __restrict__ x, const T* __restrict__ gamma, const T* __restrict__ beta,
+                                                       const double* __restrict__ stats, int64_t nvec, int C, int hw, int cg, int G,
+                                                       float inv_elems, float eps, int silu, T* __restrict__ y) {
+    constexpr int N = VecIO<T>::N;
+    const int vpp = C / N;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < nvec; e += stride) {
+        const int v = int(e % vpp);
+        const int64_t b = e / (int64_t(vpp) * hw);
+        float val[N], ga[N], be[N];
+        VecIO<T>::load(x + e * N, val);
+        if (gamma) VecIO<T>::load(gamma + v * N, ga);
+        if (beta) VecIO<T>::load(beta + v * N, be);
+        int gprev = -1;
+        float mean = 0.f, rstd = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int g = (v * N + j) / cg;
+            if (g != gprev) {
+                const double m = stats[(b * G + g) * 2] * inv_elems;
+                const double var = stats[(b * G + g) * 2 + 1] * inv_elems - m * m;
+                mean = float(m);
+                rstd = rsqrtf(fmaxf(float(var), 0.f) + eps);
+                gprev = g;
+            }
+            float t = (val[j] - mean) * rstd;
+            if (gamma) t *= ga[j];
+            if (beta) t += be[j];
+            if (silu == 1) t = t / (1.f + __expf(-t));
+            else if (silu == 2) t = fmaxf(t, 0.f);
+            val[j] = t;
+        }
+        VecIO<T>::store(y + e * N, val);
+    }
+}
+
+template <typename T>
+static int gn_launch_nhwc(const void* x, int64_t B, int C, int hw, int G, const void* gamma, const void* beta, float eps, int silu,
+                          void* y, double* stats, hipStream_t s) {
+    const int cg = C / G;
+    const int nstat = int(B) * G * 2;
+    hipLaunchKernelGGL(k_gn_zero, dim3((nstat + 255) / 256), dim3(256), 0, s, stats, nstat);
+    // pixels per workgroup: aim at ~1024 workgroups, at least one pixel per pixel lane, at most 256
+    const int vpp = C / VecIO<T>::N;
+    const int lanes = vpp < 256 ? 256 / vpp : 1;
+    int64_t pix = (B * int64_t(hw) + 1023) / 1024;
+    if (pix < lanes) pix = lanes;
+    if (pix > 256) pix = 256;
+    if (pix > hw) pix = hw;
+    const int slabs = int((hw + pix - 1) / pix);
+    hipLaunchKernelGGL(k_gn_stats_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), hw, C, cg, G, slabs, int(pix), stats);
+    const int64_t nvec = B * int64_t(hw) * C / VecIO<T>::N;
+    int64_t blocks = (nvec + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    hipLaunchKernelGGL(k_gn_apply_nhwc<T>, dim3(unsigned(blocks)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(gamma),
+                       static_cast<const T*>(beta), stats, nvec, C, hw, cg, G, 1.0f / (float(cg) * float(hw)), eps, silu, static_cast<T*>(y));
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
 template <typename T>
 static int gn_launch(const void* x, int64_t B, int C, int hw, int G, const void* gamma, const void* beta, float eps, int silu,
                      void* y, double* stats, hipStream_t s) {
@@ -160,4 +279,20 @@ extern "C" int xm3d_group_norm(const void* x, int32_t dtype, int64_t B, int32_t 
     hipStream_t s = as_stream(stream);
     if (dtype == 0) return gn_launch<float>(x, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
     return gn_launch<__hip_bfloat16>(x, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
+}
+
+extern "C" int xm3d_group_norm_nhwc(const void* x, int32_t dtype, int64_t B, int32_t C, int32_t hw, int32_t G, const void* gamma,
+                                    const void* beta, float eps, int32_t silu, void* y, double* stats_ws, void* stream) {
+    XM3D_REQUIRE(B >= 0 && C >= 1 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "group_norm_nhwc: bad shape B=%lld C=%d hw=%d G=%d",
+                 (long long)B, C, hw, G);
+    XM3D_REQUIRE(dtype == 0 || dtype == 1, "group_norm_nhwc: dtype must be 0 (f32) or 1 (bf16)");
+    if (B == 0) return XM3D_OK;
+    XM3D_REQUIRE(x && y && stats_ws, "group_norm_nhwc: null pointer");
+    const int N = dtype == 0 ? 4 : 8;
+    XM3D_REQUIRE(C % N == 0, "group_norm_nhwc: C=%d must be a multiple of %d", C, N);
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) |
+                   reinterpret_cast<uintptr_t>(beta)) & 15) == 0, "group_norm_nhwc: tensors must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    if (dtype == 0) return gn_launch_nhwc<float>(x, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
+    return gn_launch_nhwc<__hip_bfloat16>(x, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
 }

@@ -297,15 +297,21 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False):
         raise RuntimeError("group_norm: ROCm device tensor required (no CPU path)")
     if x.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError(f"group_norm: unsupported dtype {x.dtype}")
-    if not x.is_contiguous():
-        x = x.contiguous()
     B, C = x.shape[0], x.shape[1]
     hw = x.numel() // max(B * C, 1)
     for t in (weight, bias):
         if t is not None and (t.dtype != x.dtype or not t.is_contiguous() or t.numel() != C):
             raise TypeError("group_norm: weight/bias must be contiguous (C,) tensors of the input dtype")
-    y = torch.empty_like(x)
     stats = torch.empty(B * num_groups * 2, dtype=torch.float64, device=x.device)
+    nvec = 4 if x.dtype == torch.float32 else 8
+    if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last) and C % nvec == 0 and num_groups <= 64:
+        y = torch.empty_like(x)  # preserves channels_last
+        check(lib().xm3d_group_norm_nhwc(_ptr(x), 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups, _ptr(weight), _ptr(bias),
+                                         float(eps), int(silu), _ptr(y), _ptr(stats), _stream()), "xm3d_group_norm_nhwc")
+        return y
+    if not x.is_contiguous():
+        x = x.contiguous()
+    y = torch.empty_like(x)
     check(lib().xm3d_group_norm(_ptr(x), 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups, _ptr(weight), _ptr(bias),
                                 float(eps), int(silu), _ptr(y), _ptr(stats), _stream()), "xm3d_group_norm")
     return y

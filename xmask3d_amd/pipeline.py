@@ -186,26 +186,43 @@ def postprocess_view(cfg, outputs, batch, with_ablations=True, s=0):
 
 @torch.no_grad()
 def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, with_ablations=True, views_per_batch=None,
-                next_scene: SceneOnDevice | None = None):
+                next_scene: SceneOnDevice | None = None, next_matrices=None):
     """All views of one scene -> per-point class votes -> arg-max, unseen points take the nearest seen point's label.
     views_per_batch: how many views go through the model together (default: all of them, one forward per scene; 1 =
     the reference's batch-1 loop, run/infer.py:428-482).  Per-view results do not depend on the grouping.
     matrices: optional list of 4x4 voxelisation transforms (otherwise drawn from np.random like the reference).
-    next_scene: the scene that will be inferred next; its VAE-encoder graph is enqueued on the side stream as soon as this
-    scene's dense graphs are in flight, so it overlaps this scene's post-processing (software pipelining across scenes)."""
+    next_scene (+ next_matrices): the scene that will be inferred next.  Its shape-dynamic front (voxelisation, sparse 3D
+    nets) is issued on a side stream and its VAE-encoder graph on another as soon as this scene's dense graph is launched,
+    so both overlap this scene's long static graph (software pipelining across scenes); the next call picks them up."""
     voxelizer = voxelizer or default_voxelizer(cfg.voxel_size, sd.device)
     ncls = len(cfg.category_split["base_category"]) + len(cfg.category_split["novel_category"])
     votes = [torch.zeros((sd.n, ncls), dtype=torch.int32, device=sd.device) for _ in range(3 if with_ablations else 1)]
     seen = torch.zeros(sd.n, dtype=torch.bool, device=sd.device)
     nv = len(sd.views)
     step = views_per_batch or nv
+    staged = step >= nv and sd.device.type == "cuda" and getattr(model, "_dense_graphs", None) is not None and not model.training
+    pending, model._next_front = getattr(model, "_next_front", None), None
     for v0 in range(0, nv, step):
         views = list(range(v0, min(v0 + step, nv)))
-        batch = build_scene_batch(sd, views, voxelizer, None if matrices is None else [matrices[v] for v in views])
-        batch["compact_outputs"] = False  # keep all Q mask rows (dropped ones all-False): no host sync in the fusion stage
-        _, outputs = model(batch)
-        if next_scene is not None and v0 + step >= nv and step >= nv and hasattr(model, "prefetch_encoder"):
-            model.prefetch_encoder(next_scene.img_all)
+        if staged and pending is not None and pending["scene"] is sd and pending["matrices"] is matrices:
+            batch, front = pending["batch"], pending["front"]  # issued during the previous call
+        else:
+            batch = build_scene_batch(sd, views, voxelizer, None if matrices is None else [matrices[v] for v in views])
+            batch["compact_outputs"] = False  # keep all Q mask rows (dropped ones all-False): no host sync in the fusion stage
+            front = None
+        if staged:
+            front = front or model.eval_front(batch)
+            outputs = model.eval_dense(batch, front)
+            if next_scene is not None:
+                fs = model.front_stream()
+                with torch.cuda.stream(fs):
+                    nbatch = build_scene_batch(next_scene, list(range(len(next_scene.views))), voxelizer, next_matrices)
+                    nbatch["compact_outputs"] = False
+                model._next_front = dict(scene=next_scene, matrices=next_matrices, batch=nbatch,
+                                         front=model.eval_front(nbatch, stream=fs))
+            outputs = model.eval_fuse(batch, front, outputs)
+        else:
+            _, outputs = model(batch)
         for s, v in enumerate(views):
             preds = postprocess_view(cfg, outputs, batch, with_ablations, s)
             idx = sd.views[v]["idx"]

@@ -40,7 +40,8 @@ ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 def gn_act(norm: nn.GroupNorm, x, act=ACT_NONE):
     """GroupNorm followed by an activation.  Inference on a ROCm device runs the fused HIP kernel (xm3d_group_norm:
     two streaming passes instead of five library kernels); under autograd, or on the CPU-baseline path, the torch ops."""
-    if x.is_cuda and not torch.is_grad_enabled() and x.dtype in (torch.float32, torch.bfloat16) and (x.numel() // (x.shape[0] * x.shape[1])) % 8 == 0:
+    if x.is_cuda and not torch.is_grad_enabled() and x.dtype in (torch.float32, torch.bfloat16) and (
+            (x.numel() // (x.shape[0] * x.shape[1])) % 8 == 0 or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 8 == 0)):
         from . import ops
 
         w, b = norm.weight, norm.bias
@@ -157,7 +158,7 @@ class VaeEncoder(nn.Module):
         for i, lvl in enumerate(self.down):
             for j, blk in enumerate(lvl.block):
                 if i * self.num_res_blocks + j in taps:
-                    feats.append(h.contiguous())
+                    feats.append(h)
                 h = blk(h)
             if i != self.num_resolutions - 1:
                 h = lvl.downsample(h)
@@ -192,7 +193,7 @@ class VaeDecoder(nn.Module):
         for i in reversed(range(self.num_resolutions)):
             for blk in self.up[i].block:
                 if idx in taps:
-                    feats.append(h.contiguous())
+                    feats.append(h)
                     if stop_after_taps and idx == last:
                         return None, feats
                 h = blk(h)
@@ -390,7 +391,7 @@ class UNetModel(nn.Module):
         for i, m in enumerate(self.output_blocks):
             h = torch.cat([h, hs.pop()], dim=1)
             if i in taps:
-                feats.append(h.contiguous())
+                feats.append(h)
                 if stop_after_taps and i == last:
                     return None, feats
             h = m(h, emb, context)

@@ -49,6 +49,19 @@ def ensemble_logits_with_labels(logits, labels, ensemble_method="max"):
     return torch.stack(outs, dim=-1)
 
 
+def _record_stream(obj, stream):
+    """tensors allocated on one stream and read on another: tell the caching allocator about the second reader"""
+    if torch.is_tensor(obj):
+        if obj.is_cuda:
+            obj.record_stream(stream)
+    elif isinstance(obj, dict):
+        for v in obj.values():
+            _record_stream(v, stream)
+    elif isinstance(obj, (list, tuple)):
+        for v in obj:
+            _record_stream(v, stream)
+
+
 class XMASK3d(nn.Module):
     def __init__(self, cfg=None, dense_dtype=torch.float32, prune_dead_compute=True):
         super().__init__()
@@ -175,44 +188,35 @@ class XMASK3d(nn.Module):
         outputs["mask_embed_clip"] = clip_embed["mask_embed_clip"].float()
         return outputs
 
-    def enable_dense_graph(self, on=True):
+    def enable_dense_graph(self, on=True, slots=2):
         """Replay the static-shape dense branch as one HIP graph per input shape (inference only): ~2000 launch-bound
         kernels per view stop paying host launch cost.  Outputs are static buffers, valid until the next call."""
         self._dense_graphs = {} if on else None
+        self._graph_slots = max(1, int(slots))
         return self
 
-    def _graphs_for(self, img, cond):
-        """Two HIP graphs per input shape: A = VAE encoder (independent of the 3D branch), B = everything after it with
-        the VAE decoder forked beside the UNet inside the capture."""
+    def _graphs_for(self, img, cond, slot=0):
+        """Two HIP graphs per input shape and slot: A = VAE encoder (independent of the 3D branch), B = everything after it
+        with the VAE decoder forked beside the UNet inside the capture.  Slots are independent copies (own static buffers
+        and side stream) so that graph A of the next forward can run while graph B of this one is still executing."""
         key = (tuple(img.shape), img.dtype, self.dense_dtype, self.channels_last)
-        entry = self._dense_graphs.get(key)
-        if entry is None:
-            s_img, s_cond = img.clone(), cond.clone()
-            side, fork = torch.cuda.Stream(), torch.cuda.Stream()
-            side.wait_stream(torch.cuda.current_stream())
-            with torch.cuda.stream(side):
-                for _ in range(2):  # warm-up outside capture: MIOpen/hipBLASLt algorithm selection, constant caches
-                    self.dense_forward(s_img, s_cond, self.encode_vae(s_img))
-            torch.cuda.current_stream().wait_stream(side)
-            ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
-            with torch.cuda.graph(ga):
-                s_enc = self.encode_vae(s_img)
-            with torch.cuda.graph(gb):
-                s_out = self.dense_forward(s_img, s_cond, s_enc, fork)
-            entry = self._dense_graphs[key] = dict(ga=ga, gb=gb, img=s_img, cond=s_cond, out=s_out, side=side, keep=(s_enc, fork))
-        return entry
-
-    def prefetch_encoder(self, img):
-        """Enqueue the VAE-encoder graph for the NEXT forward's images on the side stream now (e.g. while the host is
-        still launching this scene's post-processing).  The next forward recognises the same `img` tensor and skips it."""
-        if self._dense_graphs is None:
-            return
-        g = self._graphs_for(img, torch.zeros(img.shape[0], 768, device=img.device))
-        g["side"].wait_stream(torch.cuda.current_stream())  # graph B of the previous forward has consumed the buffers
-        with torch.cuda.stream(g["side"]):
-            g["img"].copy_(img)
-            g["ga"].replay()
-        self._prefetched = (img.data_ptr(), tuple(img.shape), img._version)
+        if (key, slot) not in self._dense_graphs:
+            for sl in range(self._graph_slots):  # capture every slot now: nothing else is in flight at the first call
+                s_img, s_cond = img.clone(), cond.clone()
+                side, fork = torch.cuda.Stream(), torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(2 if sl == 0 else 1):  # warm-up outside capture: library algorithm selection, caches
+                        self.dense_forward(s_img, s_cond, self.encode_vae(s_img))
+                torch.cuda.current_stream().wait_stream(side)
+                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                with torch.cuda.graph(ga):
+                    s_enc = self.encode_vae(s_img)
+                with torch.cuda.graph(gb):
+                    s_out = self.dense_forward(s_img, s_cond, s_enc, fork)
+                self._dense_graphs[(key, sl)] = dict(ga=ga, gb=gb, img=s_img, cond=s_cond, out=s_out, side=side, b_done=None,
+                                                     keep=(s_enc, fork))
+        return self._dense_graphs[(key, slot)]
 
     def _dense_graphed(self, img, cond):
         g = self._graphs_for(img, cond)
@@ -222,45 +226,78 @@ class XMASK3d(nn.Module):
         g["gb"].replay()
         return dict(g["out"])
 
+    def front_stream(self):
+        """The stream `pipeline.infer_scene` runs the NEXT scene's front on (voxelisation, sparse 3D nets)."""
+        if getattr(self, "_front_stream", None) is None:
+            self._front_stream = torch.cuda.Stream()
+        return self._front_stream
+
     # ------------------------------------------------------------------ forward
+    # The eval forward has three stages.  forward() runs them back to back; pipeline.infer_scene interleaves two scenes:
+    # front(i+1) is issued on a side stream right after dense(i) is launched, so the host-bound, shape-dynamic sparse
+    # front of the next scene and its VAE-encoder graph overlap the long static graph of this one.
+    def eval_front(self, batch_input, stream=None):
+        """Stage 1 (rows a4-a7 + a8 encoder): VAE-encoder graph on its side stream, sparse 3D nets on `stream` (default:
+        the current stream).  Returns the hand-over dict for eval_dense / eval_fuse."""
+        sinput = batch_input["sinput"]
+        dev = sinput.F.device
+        img = batch_input["img"].to(dev)
+        B = img.shape[0]
+        inds = batch_input["inds_reconstruct"].to(dev)
+        graphed = self._dense_graphs is not None and not torch.is_grad_enabled()
+        front = {"graphed": graphed, "img": img, "event": None}
+        producer = stream if stream is not None else (torch.cuda.current_stream() if img.is_cuda else None)
+        if graphed:
+            slot = self._slot = (getattr(self, "_slot", -1) + 1) % self._graph_slots
+            g = front["g"] = self._graphs_for(img, torch.zeros(B, 768, device=dev), slot)
+            g["side"].wait_stream(producer)          # the images are ready
+            if g["b_done"] is not None:
+                g["side"].wait_event(g["b_done"])    # graph B that last read this slot's buffers has finished
+            with torch.cuda.stream(g["side"]):
+                g["img"].copy_(img)
+                g["ga"].replay()
+        if stream is not None:
+            with torch.cuda.stream(stream):
+                front["pred_3d"], front["cond"], front["binary_scores"] = self.encode_3d(sinput, inds, B)
+                front["event"] = torch.cuda.Event()
+                front["event"].record(stream)
+        else:
+            front["pred_3d"], front["cond"], front["binary_scores"] = self.encode_3d(sinput, inds, B)
+        return front
+
+    def eval_dense(self, batch_input, front):
+        """Stage 2 (rows a8-a17): the static-shape dense branch on the current stream."""
+        if front["event"] is not None:  # the front ran on another stream: order after it, tell the allocator about the new reader
+            cur = torch.cuda.current_stream()
+            cur.wait_event(front["event"])
+            _record_stream((batch_input, front["pred_3d"], front["cond"], front["binary_scores"]), cur)
+        if not self.prune_dead_compute:  # the reference embeds the captions in eval and never uses the result
+            self.category_head.clip.embed_text(batch_input["captions"])
+        if front["graphed"]:
+            g = front["g"]
+            cur = torch.cuda.current_stream()
+            g["cond"].copy_(front["cond"])
+            cur.wait_stream(g["side"])
+            g["gb"].replay()
+            g["b_done"] = torch.cuda.Event()
+            g["b_done"].record(cur)
+            return dict(g["out"])
+        return self.dense_forward(front["img"], front["cond"])
+
+    def eval_fuse(self, batch_input, front, outputs):
+        """Stage 3 (rows a18-a19): masks -> points, 2D/3D fusion."""
+        outputs["pred_3d"] = front["pred_3d"]
+        binary_pred = (torch.sigmoid(front["binary_scores"]) > 0.5).long()
+        mask_cls_results = outputs["pred_logits"]
+        outputs.update(self.fuse_eval(outputs, batch_input, front["binary_scores"]))
+        outputs.update({"mask_cls_results": mask_cls_results, "binary_pred": binary_pred})
+        return outputs
+
     def forward(self, batch_input):
         if self.training:
             return self.forward_train(batch_input)
-        sinput = batch_input["sinput"]
-        dev = sinput.F.device
-        img = batch_input["img"]
-        B = img.shape[0]
-        inds = batch_input["inds_reconstruct"].to(dev)
-        img = img.to(dev)
-        graphed = self._dense_graphs is not None and not torch.is_grad_enabled()
-        if graphed:
-            # VAE encoder graph on a side stream while the sparse 3D nets run on the current stream
-            cur = torch.cuda.current_stream()
-            dummy = torch.zeros(B, 768, device=dev)
-            g = self._graphs_for(img, dummy)
-            if getattr(self, "_prefetched", None) != (img.data_ptr(), tuple(img.shape), img._version):
-                g["side"].wait_stream(cur)
-                with torch.cuda.stream(g["side"]):
-                    g["img"].copy_(img)
-                    g["ga"].replay()
-            self._prefetched = None
-        pred_3d, cond, binary_scores = self.encode_3d(sinput, inds, B)
-        if not self.prune_dead_compute:  # the reference embeds the captions in eval and never uses the result
-            self.category_head.clip.embed_text(batch_input["captions"])
-        if graphed:
-            g["cond"].copy_(cond)
-            cur.wait_stream(g["side"])
-            g["gb"].replay()
-            outputs = dict(g["out"])
-        else:
-            outputs = self.dense_forward(img, cond)
-        outputs["pred_3d"] = pred_3d
-        binary_pred = (torch.sigmoid(binary_scores) > 0.5).long()
-        mask_cls_results = outputs["pred_logits"]
-        fused = self.fuse_eval(outputs, batch_input, binary_scores)
-        outputs.update(fused)
-        outputs.update({"mask_cls_results": mask_cls_results, "binary_pred": binary_pred})
-        return None, outputs
+        front = self.eval_front(batch_input)
+        return None, self.eval_fuse(batch_input, front, self.eval_dense(batch_input, front))
 
     def forward_train(self, batch_input):
         """models/xmask3d.py:182-305: Hungarian-matched mask losses (main + 9 aux), 3D CE losses on fused / pure-3D point
