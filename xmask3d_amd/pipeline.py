@@ -141,19 +141,35 @@ def nearest_valid_fill(xyz: torch.Tensor, valid: torch.Tensor):
     return fill.scatter(0, q_order, torch.where(live, r_order[nn], q_order))
 
 
-def _gate(logits, binary_pred, base, novel):
-    lb, ln = logits.clone(), logits.clone()
-    ln[:, base] = -1e10
-    lb[:, novel] = -1e10
-    return binary_pred * lb + (1 - binary_pred) * ln
+_CONSTS = {}
+
+
+def _class_consts(cfg, ncols, device):
+    """Column masks of the base / novel classes and the base-overlap vector, built once per device: creating them per call
+    means a pageable host->device copy, which blocks the host until the stream has drained (the host could then never run
+    ahead of the dense graph)."""
+    key = (id(cfg), ncols, str(device))
+    if key not in _CONSTS:
+        cs = cfg.category_split
+        base, novel, allc = list(cs["base_category"]), list(cs["novel_category"]), list(cs["all_category"])
+        bm, nm = torch.zeros(ncols, dtype=torch.bool), torch.zeros(ncols, dtype=torch.bool)
+        bm[base] = True
+        nm[novel] = True
+        overlap = torch.tensor([float(c in base) for c in allc], dtype=torch.float32)
+        _CONSTS[key] = (bm.to(device), nm.to(device), overlap.to(device))
+    return _CONSTS[key]
+
+
+def _gate(logits, binary_pred, base_mask, novel_mask):
+    """base-predicted points may only take base classes, the others only novel ones (infer.py:489-507)"""
+    return torch.where(binary_pred.bool(), logits.masked_fill(novel_mask, -1e10), logits.masked_fill(base_mask, -1e10))
 
 
 def postprocess_view(cfg, outputs, batch, with_ablations=True, s=0):
     """-> class id per visible point of batch entry `s` for the fused / 2D-only / 3D-only predictions.  Branch-free (no
     host synchronisation): an empty mask set or a fully covered view simply selects nothing."""
-    cs = cfg.category_split
-    base, novel, allc = list(cs["base_category"]), list(cs["novel_category"]), list(cs["all_category"])
     text = F.normalize(outputs["text_embed"], dim=-1)
+    base, novel, overlap = _class_consts(cfg, text.shape[0], text.device)
     scale = outputs["logit_scale"]
     offsets = batch.get("point_offsets")
     sel = slice(offsets[s], offsets[s + 1]) if offsets is not None else (batch["ori_coords"][:, 0] == s)
@@ -164,7 +180,6 @@ def postprocess_view(cfg, outputs, batch, with_ablations=True, s=0):
     masks = outputs["final_mask_3d"][s]
     if masks.shape[0] > 0:
         open_p = (scale * (F.normalize(open_emb, dim=-1) @ text.t())).softmax(dim=-1)
-        overlap = torch.tensor([float(c in base) for c in allc], device=probs.device, dtype=probs.dtype)
         covered = masks.any(0)
         q = masks.to(torch.uint8).argmax(0)  # masks are pixel-disjoint: at most one per point
         po = open_p[q]
@@ -192,8 +207,9 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
     the reference's batch-1 loop, run/infer.py:428-482).  Per-view results do not depend on the grouping.
     matrices: optional list of 4x4 voxelisation transforms (otherwise drawn from np.random like the reference).
     next_scene (+ next_matrices): the scene that will be inferred next.  Its shape-dynamic front (voxelisation, sparse 3D
-    nets) is issued on a side stream and its VAE-encoder graph on another as soon as this scene's dense graph is launched,
-    so both overlap this scene's long static graph (software pipelining across scenes); the next call picks them up."""
+    nets) is issued on a side stream and its VAE-encoder graph on another once this scene's work is enqueued (dense graph,
+    fusion, votes - the host runs ~40 ms ahead of the device there), so both overlap this scene's long static graph
+    (software pipelining across scenes); the next call picks them up."""
     voxelizer = voxelizer or default_voxelizer(cfg.voxel_size, sd.device)
     ncls = len(cfg.category_split["base_category"]) + len(cfg.category_split["novel_category"])
     votes = [torch.zeros((sd.n, ncls), dtype=torch.int32, device=sd.device) for _ in range(3 if with_ablations else 1)]
@@ -213,13 +229,6 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
         if staged:
             front = front or model.eval_front(batch)
             outputs = model.eval_dense(batch, front)
-            if next_scene is not None:
-                fs = model.front_stream()
-                with torch.cuda.stream(fs):
-                    nbatch = build_scene_batch(next_scene, list(range(len(next_scene.views))), voxelizer, next_matrices)
-                    nbatch["compact_outputs"] = False
-                model._next_front = dict(scene=next_scene, matrices=next_matrices, batch=nbatch,
-                                         front=model.eval_front(nbatch, stream=fs))
             outputs = model.eval_fuse(batch, front, outputs)
         else:
             _, outputs = model(batch)
@@ -229,6 +238,14 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
             for vt, p in zip(votes, preds):
                 if p is not None:
                     vt.index_put_((idx, p), torch.ones_like(p, dtype=torch.int32), accumulate=True)
-            seen[idx] = True
+            seen.index_fill_(0, idx, True)  # (`seen[idx] = True` uploads the scalar: a host-blocking copy)
     fill = nearest_valid_fill(sd.points, seen)  # unseen points take the label of the nearest seen point (infer.py:682-694)
-    return [vt.argmax(1)[fill] for vt in votes]
+    result = [vt.argmax(1)[fill] for vt in votes]
+    if staged and next_scene is not None:
+        # everything of this scene is enqueued behind its dense graph; the host is free to issue the next scene's front
+        fs = model.front_stream()
+        with torch.cuda.stream(fs):
+            nbatch = build_scene_batch(next_scene, list(range(len(next_scene.views))), voxelizer, next_matrices)
+            nbatch["compact_outputs"] = False
+        model._next_front = dict(scene=next_scene, matrices=next_matrices, batch=nbatch, front=model.eval_front(nbatch, stream=fs))
+    return result

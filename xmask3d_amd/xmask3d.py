@@ -366,6 +366,13 @@ class XMASK3d(nn.Module):
         n_scene = (len(offsets) - 1) if offsets is not None else int(ori_coords[:, 0].max().item()) + 1
         Q = masks.shape[1]
         qidx = torch.arange(Q, device=dev).view(-1, 1, 1)
+        ck = (str(dev), outputs["pred_logits"].shape[-1])
+        if getattr(self, "_fuse_cols", (None,))[0] != ck:  # built once: a per-call host->device copy would stall the host
+            bc, nc = torch.zeros(ck[1], dtype=torch.bool), torch.zeros(ck[1], dtype=torch.bool)
+            bc[base_cat + [num_classes]] = True
+            nc[novel_cat] = True
+            self._fuse_cols = (ck, bc.to(dev), nc.to(dev))
+        base_cols, novel_cols = self._fuse_cols[1:]
         out, out2d, out3d, mask3d_l, open_l = [], [], [], [], []
         for s in range(n_scene):
             sel = slice(offsets[s], offsets[s + 1]) if offsets is not None else (ori_coords[:, 0] == s)
@@ -380,10 +387,7 @@ class XMASK3d(nn.Module):
             cover = m3d_full.float()
             bp = (scene_scores * cover).sum(1) / (cover.sum(1) + 1e-10)
             is_base = (bp > cfg.binary_2d_thresh).view(-1, 1)
-            l_novel, l_base = cls.clone(), cls.clone()
-            l_novel[:, base_cat + [num_classes]] = -1e10
-            l_base[:, novel_cat] = -1e10
-            modified = is_base * l_base + (~is_base) * l_novel
+            modified = torch.where(is_base, cls.masked_fill(novel_cols, -1e10), cls.masked_fill(base_cols, -1e10))
             scores = F.softmax(modified, dim=-1).max(-1)[0]
             mask_pred = m.sigmoid()
             keep = keep_full & (scores > cfg.scores_keep_thresh)
