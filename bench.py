@@ -159,6 +159,8 @@ def main():
     model.set_dense_dtype(dense_dtype)
     if args.channels_last:
         model.set_channels_last(True)
+    if dense_dtype == torch.bfloat16:
+        model.cast_head_weights()
     if not args.no_graph:
         model.enable_dense_graph()
 

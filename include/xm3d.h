@@ -148,9 +148,22 @@ int xm3d_affine_act(const float* x, int64_t n, int32_t c, const float* scale, co
  * ------------------------------------------------------------------------- */
 int xm3d_group_norm(const void* x, int32_t dtype, int64_t B, int32_t C, int32_t hw, int32_t G, const void* gamma,
                     const void* beta, float eps, int32_t silu, void* y, double* stats_ws, void* stream);
-/* Same for channels-last activations: x, y are (B, H*W, C) contiguous (NHWC); C a multiple of 4 (f32) / 8 (bf16), G <= 64. */
-int xm3d_group_norm_nhwc(const void* x, int32_t dtype, int64_t B, int32_t C, int32_t hw, int32_t G, const void* gamma,
-                         const void* beta, float eps, int32_t silu, void* y, double* stats_ws, void* stream);
+/* Same for channels-last activations: x, y are (B, H*W, C) contiguous (NHWC); C a multiple of 4 (f32) / 8 (bf16), G <= 64.
+ * shift (optional, dtype of x): a per-channel term added to x before the normalisation, y = GN(x + shift[c]) - the bias of
+ * the convolution that produced x and/or the timestep-embedding term of ldm's ResBlock (openaimodel.py ResBlock._forward),
+ * which then need no pass of their own.  shift_bstride = 0: one (C) vector for all samples; = C: a (B, C) matrix. */
+int xm3d_group_norm_nhwc(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,
+                         int32_t G, const void* gamma, const void* beta, float eps, int32_t silu, void* y, double* stats_ws,
+                         void* stream);
+
+/* ---- pointwise fusions around the frozen nets' convolutions / GEMMs (channels-last, dtype 0 = f32, 1 = bf16) ----
+ * out = a + b + bias[c] over (pixels, C) NHWC tensors; a may be NULL (out = b + bias).  Replaces the separate broadcast
+ * bias kernel PyTorch-ROCm appends to every MIOpen convolution plus the residual add (ldm ResnetBlock.forward `x + h`). */
+int xm3d_bias_residual_nhwc(const void* a, const void* b, const void* bias, int32_t dtype, int64_t pixels, int32_t C, void* out,
+                            void* stream);
+/* GEGLU gate of ldm's FeedForward (attention.py GEGLU.forward): x (rows, 2*D) contiguous -> out (rows, D) =
+ * x[:, :D] * gelu(x[:, D:]) (exact erf GELU, f32 arithmetic). */
+int xm3d_geglu(const void* x, int32_t dtype, int64_t rows, int32_t D, void* out, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Multi-scale deformable attention (replaces the pybind module

@@ -167,3 +167,49 @@ def test_nearest_valid_fill_matches_bruteforce(dev):
     assert (pipeline.nearest_valid_fill(xyz.to(dev), torch.ones(7000, dtype=torch.bool, device=dev)).cpu() == torch.arange(7000)).all()
     none = pipeline.nearest_valid_fill(xyz.to(dev), torch.zeros(7000, dtype=torch.bool, device=dev)).cpu()
     assert int(none.min()) >= 0 and int(none.max()) < 7000
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_bilinear_down_bit_identical_on_device(dev, dtype):
+    import torch.nn.functional as F
+    from xmask3d_amd.mask_head import bilinear_down
+
+    torch.manual_seed(0)
+    x = torch.randn(5, 50, 128, 128, device=dev).to(dtype)
+    with torch.no_grad():
+        for t in (16, 32, 64):
+            assert torch.equal(bilinear_down(x, (t, t)), F.interpolate(x, size=(t, t), mode="bilinear", align_corners=False))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_pointwise_fusions_match_torch(dev, dtype):
+    """xm3d_bias_residual_nhwc, xm3d_geglu, xm3d_group_norm_nhwc(shift) against the torch op chains they replace"""
+    import torch.nn.functional as F
+    from xmask3d_amd import ops
+
+    torch.manual_seed(0)
+    tol = 1e-6 if dtype == torch.float32 else 2e-2
+    a = torch.randn(3, 64, 24, 40, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    b = torch.randn(3, 64, 24, 40, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    bias = torch.randn(64, device=dev).to(dtype)
+    ref = a.float() + b.float() + bias.float().view(1, -1, 1, 1)
+    out = ops.bias_residual(a, b, bias)
+    assert out.is_contiguous(memory_format=torch.channels_last) and out.dtype == dtype
+    assert (out.float() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    out = ops.bias_residual(None, b, bias)
+    assert (out.float() - (b.float() + bias.float().view(1, -1, 1, 1))).abs().max().item() <= tol * ref.abs().max().item()
+    x = torch.randn(4, 77, 256, device=dev).to(dtype)
+    u, g = x.float().chunk(2, -1)
+    ref = u * F.gelu(g)
+    out = ops.geglu(x)
+    assert out.shape == (4, 77, 128) and (out.float() - ref).abs().max().item() <= tol * ref.abs().max().item()
+    # GroupNorm with a per-sample shift == GroupNorm(x + shift)
+    w, bb = torch.randn(64, device=dev).to(dtype), torch.randn(64, device=dev).to(dtype)
+    for shift in (torch.randn(64, device=dev).to(dtype), torch.randn(3, 64, device=dev).to(dtype)):
+        xs = a.float() + shift.float().view(-1, 64, 1, 1)
+        ref = F.silu(F.group_norm(xs, 32, w.float(), bb.float(), 1e-5))
+        out = ops.group_norm(a, 32, w, bb, 1e-5, 1, shift)
+        assert out.is_contiguous(memory_format=torch.channels_last)
+        assert (out.float() - ref).abs().max().item() <= max(tol, 2e-5) * max(ref.abs().max().item(), 1.0)

@@ -35,3 +35,17 @@ def test_synthetic_scenes_are_deterministic_and_shaped():
     vis, rows, cols = syn.view_subset(s1a, 0)
     assert 400 < vis.sum() < 65000 and rows.shape == cols.shape == (int(vis.sum()),)
     assert rows.min() >= 10 and rows.max() < 230 and cols.min() >= 10 and cols.max() < 310
+
+
+def test_bilinear_down_is_bit_identical_to_interpolate():
+    """mask_head.bilinear_down replaces F.interpolate(bilinear) for even integer shrink factors (odise.py:445-491 attention masks)"""
+    import torch
+    import torch.nn.functional as F
+    from xmask3d_amd.mask_head import bilinear_down
+
+    torch.manual_seed(0)
+    x = torch.randn(2, 5, 128, 128)
+    with torch.no_grad():
+        for t in (16, 32, 64):
+            assert torch.equal(bilinear_down(x, (t, t)), F.interpolate(x, size=(t, t), mode="bilinear", align_corners=False))
+        assert torch.equal(bilinear_down(x, (48, 48)), F.interpolate(x, size=(48, 48), mode="bilinear", align_corners=False))  # fallback

@@ -44,7 +44,9 @@ _SIGS = {
     "xm3d_bn_stats": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "xm3d_affine_act": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
     "xm3d_group_norm": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp, c_vp]),
-    "xm3d_group_norm_nhwc": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp, c_vp]),
+    "xm3d_group_norm_nhwc": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp, c_vp]),
+    "xm3d_bias_residual_nhwc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
+    "xm3d_geglu": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "xm3d_nearest_index": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_msda_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp]),
     "xm3d_msda_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp, c_vp, c_vp]),

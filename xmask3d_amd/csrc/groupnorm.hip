@@ -11,44 +11,9 @@
 #include <hip/hip_bf16.h>
 
 #include "common.h"
+#include "vecio.h"
 
 namespace xm3d {
-
-template <typename T>
-struct VecIO;
-template <>
-struct VecIO<float> {
-    static constexpr int N = 4;
-    __device__ static void load(const float* p, float (&v)[4]) {
-        const float4 t = *reinterpret_cast<const float4*>(p);
-        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
-    }
-    __device__ static void store(float* p, const float (&v)[4]) { *reinterpret_cast<float4*>(p) = make_float4(v[0], v[1], v[2], v[3]); }
-    __device__ static float scalar(const float* p) { return *p; }
-};
-template <>
-struct VecIO<__hip_bfloat16> {
-    static constexpr int N = 8;
-    __device__ static void load(const __hip_bfloat16* p, float (&v)[8]) {
-        const uint4 t = *reinterpret_cast<const uint4*>(p);
-        const unsigned w[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            v[2 * i] = __uint_as_float(w[i] << 16);
-            v[2 * i + 1] = __uint_as_float(w[i] & 0xFFFF0000u);
-        }
-    }
-    __device__ static void store(__hip_bfloat16* p, const float (&v)[8]) {
-        unsigned w[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const __hip_bfloat16 lo = __float2bfloat16(v[2 * i]), hi = __float2bfloat16(v[2 * i + 1]);
-            w[i] = unsigned(*reinterpret_cast<const unsigned short*>(&lo)) | (unsigned(*reinterpret_cast<const unsigned short*>(&hi)) << 16);
-        }
-        *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
-    }
-    __device__ static float scalar(const __hip_bfloat16* p) { return __bfloat162float(*p); }
-};
 
 constexpr int GN_SLICE = 16384;  // elements per workgroup in the statistics pass
 
@@ -133,7 +98,7 @@ __global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x, const
 // (workgroup, group).  Apply: per element group lookup (a vector may straddle two groups when C/G < N).
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_gn_stats_nhwc(const T* __restrict__ x, int hw, int C, int cg, int G, int slabs, int pix,
+__global__ __launch_bounds__(256) void k_gn_stats_nhwc(const T* __restrict__ x, const T* __restrict__ shift, int shift_bstride, int hw, int C, int cg, int G, int slabs, int pix,
                                                        double* __restrict__ stats) {
     constexpr int N = VecIO<T>::N;
     __shared__ float sm[2 * 64];  // G <= 64
@@ -148,14 +113,16 @@ __global__ __launch_bounds__(256) void k_gn_stats_nhwc(const T* __restrict__ x, 
         const int lanes = vpp < 256 ? 256 / vpp : 1;  // pixel lanes sharing this vector column
         const int pl = vpp < 256 ? threadIdx.x / vpp : 0;
         if (pl >= lanes) continue;
-        float s[N], ss[N];
+        float s[N], ss[N], sh[N];
 #pragma unroll
-        for (int j = 0; j < N; ++j) s[j] = ss[j] = 0.f;
+        for (int j = 0; j < N; ++j) s[j] = ss[j] = sh[j] = 0.f;
+        if (shift) VecIO<T>::load(shift + int64_t(b) * shift_bstride + v * N, sh);
         for (int p = p0 + pl; p < p1; p += lanes) {
             float val[N];
             VecIO<T>::load(base + int64_t(p) * C + v * N, val);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
+                val[j] += sh[j];
                 s[j] += val[j];
                 ss[j] = fmaf(val[j], val[j], ss[j]);
             }
@@ -185,8 +152,8 @@ __global__ __launch_bounds__(256) void k_gn_stats_nhwc(const T* __restrict__ x, 
 }
 
 template <typename T>
-__global__ __launch_bounds__(256) void k_gn_apply_nhwc(const T* __restrict__ x, const T* __restrict__ gamma, const T* __restrict__ beta,
-                                                       const double* __restrict__ stats, int64_t nvec, int C, int hw, int cg, int G,
+__global__ __launch_bounds__(256) void k_gn_apply_nhwc(const T* __restrict__ x, const T* __restrict__ shift, int shift_bstride,
+                                                       const T* __restrict__ gamma, const T* __restrict__ beta, const double* __restrict__ stats, int64_t nvec, int C, int hw, int cg, int G,
                                                        float inv_elems, float eps, int silu, T* __restrict__ y) {
     constexpr int N = VecIO<T>::N;
     const int vpp = C / N;
@@ -196,6 +163,12 @@ __global__ __launch_bounds__(256) void k_gn_apply_nhwc(const T* __restrict__ x, 
         const int64_t b = e / (int64_t(vpp) * hw);
         float val[N], ga[N], be[N];
         VecIO<T>::load(x + e * N, val);
+        if (shift) {
+            float sh[N];
+            VecIO<T>::load(shift + b * shift_bstride + v * N, sh);
+#pragma unroll
+            for (int j = 0; j < N; ++j) val[j] += sh[j];
+        }
         if (gamma) VecIO<T>::load(gamma + v * N, ga);
         if (beta) VecIO<T>::load(beta + v * N, be);
         int gprev = -1;
@@ -222,7 +195,7 @@ __global__ __launch_bounds__(256) void k_gn_apply_nhwc(const T* __restrict__ x, 
 }
 
 template <typename T>
-static int gn_launch_nhwc(const void* x, int64_t B, int C, int hw, int G, const void* gamma, const void* beta, float eps, int silu,
+static int gn_launch_nhwc(const void* x, const void* shift, int shift_bstride, int64_t B, int C, int hw, int G, const void* gamma, const void* beta, float eps, int silu,
                           void* y, double* stats, hipStream_t s) {
     const int cg = C / G;
     const int nstat = int(B) * G * 2;
@@ -235,12 +208,12 @@ static int gn_launch_nhwc(const void* x, int64_t B, int C, int hw, int G, const 
     if (pix > 256) pix = 256;
     if (pix > hw) pix = hw;
     const int slabs = int((hw + pix - 1) / pix);
-    hipLaunchKernelGGL(k_gn_stats_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), hw, C, cg, G, slabs, int(pix), stats);
+    hipLaunchKernelGGL(k_gn_stats_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift), shift_bstride, hw, C, cg, G, slabs, int(pix), stats);
     const int64_t nvec = B * int64_t(hw) * C / VecIO<T>::N;
     int64_t blocks = (nvec + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_gn_apply_nhwc<T>, dim3(unsigned(blocks)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(gamma),
-                       static_cast<const T*>(beta), stats, nvec, C, hw, cg, G, 1.0f / (float(cg) * float(hw)), eps, silu, static_cast<T*>(y));
+    hipLaunchKernelGGL(k_gn_apply_nhwc<T>, dim3(unsigned(blocks)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift), shift_bstride,
+                       static_cast<const T*>(gamma), static_cast<const T*>(beta), stats, nvec, C, hw, cg, G, 1.0f / (float(cg) * float(hw)), eps, silu, static_cast<T*>(y));
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
@@ -257,8 +230,8 @@ static int gn_launch(const void* x, int64_t B, int C, int hw, int G, const void*
     const int64_t nvec = B * C * int64_t(hw) / VecIO<T>::N;
     int64_t blocks = (nvec + 255) / 256;
     if (blocks > 4096) blocks = 4096;
-    hipLaunchKernelGGL(k_gn_apply<T>, dim3(unsigned(blocks)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(gamma),
-                       static_cast<const T*>(beta), stats, nvec, C, hw, cg, 1.0f / float(group_elems), eps, silu, static_cast<T*>(y));
+    hipLaunchKernelGGL(k_gn_apply<T>, dim3(unsigned(blocks)), dim3(256), 0, s, static_cast<const T*>(x),
+                       static_cast<const T*>(gamma), static_cast<const T*>(beta), stats, nvec, C, hw, cg, 1.0f / float(group_elems), eps, silu, static_cast<T*>(y));
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
@@ -281,8 +254,9 @@ extern "C" int xm3d_group_norm(const void* x, int32_t dtype, int64_t B, int32_t 
     return gn_launch<__hip_bfloat16>(x, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
 }
 
-extern "C" int xm3d_group_norm_nhwc(const void* x, int32_t dtype, int64_t B, int32_t C, int32_t hw, int32_t G, const void* gamma,
-                                    const void* beta, float eps, int32_t silu, void* y, double* stats_ws, void* stream) {
+extern "C" int xm3d_group_norm_nhwc(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,
+                                    int32_t G, const void* gamma, const void* beta, float eps, int32_t silu, void* y, double* stats_ws,
+                                    void* stream) {
     XM3D_REQUIRE(B >= 0 && C >= 1 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "group_norm_nhwc: bad shape B=%lld C=%d hw=%d G=%d",
                  (long long)B, C, hw, G);
     XM3D_REQUIRE(dtype == 0 || dtype == 1, "group_norm_nhwc: dtype must be 0 (f32) or 1 (bf16)");
@@ -291,8 +265,10 @@ extern "C" int xm3d_group_norm_nhwc(const void* x, int32_t dtype, int64_t B, int
     const int N = dtype == 0 ? 4 : 8;
     XM3D_REQUIRE(C % N == 0, "group_norm_nhwc: C=%d must be a multiple of %d", C, N);
     XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) |
-                   reinterpret_cast<uintptr_t>(beta)) & 15) == 0, "group_norm_nhwc: tensors must be 16-byte aligned");
+                   reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0,
+                 "group_norm_nhwc: tensors must be 16-byte aligned");
+    XM3D_REQUIRE(shift_bstride == 0 || shift_bstride == C, "group_norm_nhwc: shift_bstride must be 0 (shared) or C (per sample)");
     hipStream_t s = as_stream(stream);
-    if (dtype == 0) return gn_launch_nhwc<float>(x, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
-    return gn_launch_nhwc<__hip_bfloat16>(x, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
+    if (dtype == 0) return gn_launch_nhwc<float>(x, shift, shift_bstride, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
+    return gn_launch_nhwc<__hip_bfloat16>(x, shift, shift_bstride, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
 }

@@ -239,9 +239,10 @@ class CrossAttentionLayer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, tgt, memory, memory_mask=None, pos=None, query_pos=None):
-        tgt2 = self.multihead_attn(query=tgt + query_pos, key=memory + pos, value=memory, attn_mask=memory_mask,
-                                   need_weights=False)[0]
+    def forward(self, tgt, memory, memory_mask=None, pos=None, query_pos=None, key=None):
+        """key: memory + pos when the caller has it already (the same level feeds three layers)"""
+        tgt2 = self.multihead_attn(query=tgt + query_pos, key=memory + pos if key is None else key, value=memory,
+                                   attn_mask=memory_mask, need_weights=False)[0]
         return self.norm(tgt + tgt2)
 
 
@@ -311,6 +312,27 @@ class PooledMaskEmbed(nn.Module):
                 "logit_scale": torch.clamp(self.logit_scale.exp(), max=100)}
 
 
+def bilinear_down(x, size):
+    """F.interpolate(x, size, mode="bilinear", align_corners=False) for the case this decoder meets: shrinking by an even
+    integer factor s.  The source coordinate of output pixel i is s*i + s/2 - 1/2, i.e. exactly half way between input
+    pixels s*i + s/2 - 1 and s*i + s/2: both weights are 0.5, so the result is the mean of the central 2x2 of every s x s
+    block.  Scaling by 0.5 commutes with rounding, so summed in the library kernel's order - row pairs first on the
+    device, left to right on the host, f32 accumulation for 16-bit inputs - the result is bit-identical
+    (tests/test_gpu_msda_fuse.py, tests/test_host.py) at a fraction of the cost: the device kernel parallelises over output
+    pixels only and loops over all B*Q maps."""
+    H, W = x.shape[-2:]
+    h, w = int(size[0]), int(size[1])
+    if torch.is_grad_enabled() or H % h or W % w or (H // h) % 2 or (W // w) % 2:
+        return F.interpolate(x, size=(h, w), mode="bilinear", align_corners=False)
+    sh, sw = H // h, W // w
+    oh, ow = sh // 2 - 1, sw // 2 - 1
+    xf = x.float() if x.dtype in (torch.bfloat16, torch.float16) else x
+    a, b = xf[..., oh::sh, ow::sw], xf[..., oh::sh, ow + 1::sw]
+    c, d = xf[..., oh + 1::sh, ow::sw], xf[..., oh + 1::sh, ow + 1::sw]
+    y = ((a + b) + (c + d)) * 0.25 if x.is_cuda else (a + b + c + d) * 0.25
+    return y.to(x.dtype)
+
+
 class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
     def __init__(self, *, in_channels, mask_classification=True, num_classes, hidden_dim, num_queries, nheads,
                  dim_feedforward, dec_layers, pre_norm, mask_dim, enforce_input_project, class_embed=None,
@@ -352,6 +374,7 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
             pos.append(self.pe_layer(x[i], None).flatten(2).permute(2, 0, 1))
             src.append((self.input_proj[i](x[i]).flatten(2) + self.level_embed.weight[i][None, :, None]).permute(2, 0, 1))
         bs = src[0].shape[1]
+        keys = [s_ + p_ for s_, p_ in zip(src, pos)]  # once per level instead of once per layer (same values)
         query_embed = self.query_embed.weight.unsqueeze(1).repeat(1, bs, 1)
         output = self.query_feat.weight.unsqueeze(1).repeat(1, bs, 1)
         cls_l, mask_l, extra_l = [], [], []
@@ -364,7 +387,7 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
             full = attn_mask.all(dim=-1, keepdim=True)
             attn_mask = attn_mask & ~full
             output = self.transformer_cross_attention_layers[i](output, src[lvl], memory_mask=attn_mask, pos=pos[lvl],
-                                                                query_pos=query_embed)
+                                                                query_pos=query_embed, key=keys[lvl])
             output = self.transformer_self_attention_layers[i](output, query_pos=query_embed)
             output = self.transformer_ffn_layers[i](output)
             c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[(i + 1) % self.num_feature_levels],
@@ -387,7 +410,7 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
         extra = {}
         if self.post_mask_embed is not None and with_embed:
             extra.update(self.post_mask_embed(decoder_output, mask_embed, mask_features, outputs_class, outputs_mask))
-        attn_mask = F.interpolate(outputs_mask, size=attn_mask_target_size, mode="bilinear", align_corners=False)
+        attn_mask = bilinear_down(outputs_mask, attn_mask_target_size)
         attn_mask = (attn_mask.sigmoid().flatten(2).unsqueeze(1).repeat(1, self.num_heads, 1, 1).flatten(0, 1) < 0.5).bool()
         return outputs_class, outputs_mask, attn_mask.detach(), extra
 

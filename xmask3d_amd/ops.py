@@ -290,9 +290,15 @@ def affine_act(x, scale=None, shift=None, residual=None, relu=False, out=None):
 
 
 # ---------------------------------------------------------------- fused GroupNorm(+SiLU)
-def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False):
-    """NCHW (or (B,C,L)) f32/bf16 device tensor -> same shape/dtype; statistics in f64, math in f32.
-    silu: False/0 none, True/1 SiLU, 2 ReLU fused after the affine."""
+def is_nhwc(x):
+    """4-D device tensor stored channels-last (and not also NCHW-contiguous)"""
+    return x.dim() == 4 and x.is_cuda and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
+
+
+def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False, shift=None):
+    """NCHW, channels-last or (B,C,L) f32/bf16 device tensor -> same shape/dtype/layout; statistics in f64, math in f32.
+    silu: False/0 none, True/1 SiLU, 2 ReLU fused after the affine.
+    shift: optional (C,) or (B,C) term added to x before normalising (conv bias / embedding term folded in)."""
     if not x.is_cuda:
         raise RuntimeError("group_norm: ROCm device tensor required (no CPU path)")
     if x.dtype not in (torch.float32, torch.bfloat16):
@@ -304,17 +310,49 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False):
             raise TypeError("group_norm: weight/bias must be contiguous (C,) tensors of the input dtype")
     stats = torch.empty(B * num_groups * 2, dtype=torch.float64, device=x.device)
     nvec = 4 if x.dtype == torch.float32 else 8
-    if x.dim() == 4 and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last) and C % nvec == 0 and num_groups <= 64:
+    if is_nhwc(x) and C % nvec == 0 and num_groups <= 64:
         y = torch.empty_like(x)  # preserves channels_last
-        check(lib().xm3d_group_norm_nhwc(_ptr(x), 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups, _ptr(weight), _ptr(bias),
-                                         float(eps), int(silu), _ptr(y), _ptr(stats), _stream()), "xm3d_group_norm_nhwc")
+        bstride = 0
+        if shift is not None:
+            shift = shift.to(x.dtype).contiguous()
+            if shift.numel() not in (C, B * C):
+                raise TypeError("group_norm: shift must have C or B*C elements")
+            bstride = C if (shift.numel() == B * C and B > 1) else 0
+        check(lib().xm3d_group_norm_nhwc(_ptr(x), _ptr(shift), bstride, 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups,
+                                         _ptr(weight), _ptr(bias), float(eps), int(silu), _ptr(y), _ptr(stats), _stream()),
+              "xm3d_group_norm_nhwc")
         return y
+    if shift is not None:
+        x = x + shift.to(x.dtype).reshape(-1, C, *([1] * (x.dim() - 2)))
     if not x.is_contiguous():
         x = x.contiguous()
     y = torch.empty_like(x)
     check(lib().xm3d_group_norm(_ptr(x), 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups, _ptr(weight), _ptr(bias),
                                 float(eps), int(silu), _ptr(y), _ptr(stats), _stream()), "xm3d_group_norm")
     return y
+
+
+def bias_residual(a, b, bias):
+    """out = a + b + bias[c] for channels-last (B,C,H,W) f32/bf16 device tensors; a may be None."""
+    if not is_nhwc(b) or (a is not None and (not is_nhwc(a) or a.shape != b.shape or a.dtype != b.dtype)):
+        raise TypeError("bias_residual: channels-last device tensors of one shape/dtype required")
+    if b.dtype not in (torch.float32, torch.bfloat16) or bias.dtype != b.dtype or bias.numel() != b.shape[1]:
+        raise TypeError("bias_residual: unsupported dtype / bias shape")
+    out = torch.empty_like(b)
+    Bn, C, H, W = b.shape
+    check(lib().xm3d_bias_residual_nhwc(_ptr(a), _ptr(b), _ptr(bias.contiguous()), 0 if b.dtype == torch.float32 else 1, Bn * H * W, C,
+                                        _ptr(out), _stream()), "xm3d_bias_residual_nhwc")
+    return out
+
+
+def geglu(x):
+    """x (..., 2D) contiguous f32/bf16 device tensor -> (..., D) = x[..., :D] * gelu(x[..., D:])"""
+    if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or not x.is_contiguous() or x.shape[-1] % 2:
+        raise TypeError("geglu: contiguous f32/bf16 device tensor with an even last dimension required")
+    D = x.shape[-1] // 2
+    out = torch.empty((*x.shape[:-1], D), dtype=x.dtype, device=x.device)
+    check(lib().xm3d_geglu(_ptr(x), 0 if x.dtype == torch.float32 else 1, x.numel() // (2 * D), D, _ptr(out), _stream()), "xm3d_geglu")
+    return out
 
 
 # ---------------------------------------------------------------- deformable attention

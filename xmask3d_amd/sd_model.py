@@ -37,9 +37,28 @@ def group_norm(c, eps):
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
 
 
-def gn_act(norm: nn.GroupNorm, x, act=ACT_NONE):
+def fused_nhwc(x):
+    """inference on a ROCm device with channels-last activations: the path where conv biases / embedding terms are folded
+    into the GroupNorm and residual kernels (xm3d_group_norm_nhwc shift, xm3d_bias_residual_nhwc)"""
+    return (x.is_cuda and not torch.is_grad_enabled() and x.dtype in (torch.float32, torch.bfloat16) and x.dim() == 4
+            and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 8 == 0)
+
+
+def conv_nobias(conv: nn.Conv2d, x):
+    return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+def bias_residual(skip, h, bias):
+    """skip + h + bias[c] in one pass (skip may be None)"""
+    from . import ops
+
+    return ops.bias_residual(skip, h, bias.to(h.dtype))
+
+
+def gn_act(norm: nn.GroupNorm, x, act=ACT_NONE, shift=None):
     """GroupNorm followed by an activation.  Inference on a ROCm device runs the fused HIP kernel (xm3d_group_norm:
-    two streaming passes instead of five library kernels); under autograd, or on the CPU-baseline path, the torch ops."""
+    two streaming passes instead of five library kernels); under autograd, or on the CPU-baseline path, the torch ops.
+    shift: (C,) or (B,C) term added to x first (a folded conv bias / embedding term)."""
     if x.is_cuda and not torch.is_grad_enabled() and x.dtype in (torch.float32, torch.bfloat16) and (
             (x.numel() // (x.shape[0] * x.shape[1])) % 8 == 0 or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 8 == 0)):
         from . import ops
@@ -47,7 +66,9 @@ def gn_act(norm: nn.GroupNorm, x, act=ACT_NONE):
         w, b = norm.weight, norm.bias
         if w is not None and w.dtype != x.dtype:
             w, b = w.to(x.dtype), b.to(x.dtype)
-        return ops.group_norm(x, norm.num_groups, w, b, norm.eps, act)
+        return ops.group_norm(x, norm.num_groups, w, b, norm.eps, act, shift)
+    if shift is not None:
+        x = x + shift.to(x.dtype).reshape(-1, x.shape[1], 1, 1)
     y = norm(x)
     if act == ACT_SILU:
         return y * torch.sigmoid(y)
@@ -67,6 +88,14 @@ class VaeResBlock(nn.Module):
             self.nin_shortcut = nn.Conv2d(cin, cout, 1)
 
     def forward(self, x, temb=None):
+        if fused_nhwc(x):  # conv1's bias rides in norm2's shift, conv2's (and the shortcut's) in the residual add
+            h = conv_nobias(self.conv1, gn_act(self.norm1, x, ACT_SILU))
+            h = conv_nobias(self.conv2, gn_act(self.norm2, h, ACT_SILU, self.conv1.bias))
+            bias = self.conv2.bias
+            if self.in_channels != self.out_channels:
+                x = conv_nobias(self.nin_shortcut, x)
+                bias = bias + self.nin_shortcut.bias
+            return bias_residual(x, h, bias)
         h = self.conv1(gn_act(self.norm1, x, ACT_SILU))
         h = self.conv2(gn_act(self.norm2, h, ACT_SILU))
         if self.in_channels != self.out_channels:
@@ -93,6 +122,8 @@ class VaeAttnBlock(nn.Module):
         v = self.v(h).reshape(b, 1, c, hh * ww).transpose(2, 3)
         o = F.scaled_dot_product_attention(q, k, v)  # scale = c^-0.5
         o = o.transpose(2, 3).reshape(b, c, hh, ww)
+        if fused_nhwc(x) and fused_nhwc(o):
+            return bias_residual(x, conv_nobias(self.proj_out, o), self.proj_out.bias)
         return x + self.proj_out(o)
 
 
@@ -230,6 +261,15 @@ class UNetResBlock(nn.Module):
         self.skip_connection = nn.Identity() if cin == cout else nn.Conv2d(cin, cout, 1)
 
     def forward(self, x, emb):
+        if fused_nhwc(x):  # first conv's bias + the embedding term ride in the second GroupNorm's shift
+            h = conv_nobias(self.in_layers[2], gn_act(self.in_layers[0], x, ACT_SILU))
+            shift = self.emb_layers(emb).to(h.dtype) + self.in_layers[2].bias
+            h = conv_nobias(self.out_layers[3], gn_act(self.out_layers[0], h, ACT_SILU, shift))
+            bias = self.out_layers[3].bias
+            if not isinstance(self.skip_connection, nn.Identity):
+                x = conv_nobias(self.skip_connection, x)
+                bias = bias + self.skip_connection.bias
+            return bias_residual(x, h, bias)
         h = self.in_layers[2](gn_act(self.in_layers[0], x, ACT_SILU))
         h = h + self.emb_layers(emb).to(h.dtype)[:, :, None, None]
         return self.skip_connection(x) + self.out_layers[3](gn_act(self.out_layers[0], h, ACT_SILU))
@@ -263,7 +303,12 @@ class GEGLU(nn.Module):
         self.proj = nn.Linear(dim_in, dim_out * 2)
 
     def forward(self, x):
-        x, gate = self.proj(x).chunk(2, dim=-1)
+        y = self.proj(x)
+        if y.is_cuda and not torch.is_grad_enabled() and y.dtype in (torch.float32, torch.bfloat16) and y.shape[-1] % 16 == 0:
+            from . import ops
+
+            return ops.geglu(y.contiguous())
+        x, gate = y.chunk(2, dim=-1)
         return x * F.gelu(gate)
 
 
@@ -304,6 +349,8 @@ class SpatialTransformer(nn.Module):
         for blk in self.transformer_blocks:
             y = blk(y, context.to(y.dtype))
         y = y.transpose(1, 2).reshape(b, -1, h, w)
+        if fused_nhwc(x) and fused_nhwc(y):
+            return bias_residual(x, conv_nobias(self.proj_out, y), self.proj_out.bias)
         return x + self.proj_out(y)
 
 

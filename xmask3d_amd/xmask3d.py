@@ -118,6 +118,24 @@ class XMASK3d(nn.Module):
         self.criterion.clip.clip.visual.to(dense_dtype)
         return self
 
+    def cast_head_weights(self, dtype=torch.bfloat16):
+        """Inference only: hold the GEMM / convolution weights of the trainable heads that run under bf16 autocast (feature
+        projections, pixel decoder, transformer decoder) in bf16, so that autocast finds nothing to cast - otherwise every
+        forward (and every graph replay) re-casts ~500 fp32 weight tensors.  Normalisation, embedding and positional
+        parameters keep fp32.  The values are the ones autocast would have produced; fp32 masters are lost, so do not train
+        this instance afterwards."""
+        for root in (self.backbone.feature_projections, self.sem_seg_head):
+            for m in root.modules():
+                if isinstance(m, (nn.Linear, nn.Conv2d)):
+                    m.weight.data = m.weight.data.to(dtype)
+                    if m.bias is not None:
+                        m.bias.data = m.bias.data.to(dtype)
+                elif isinstance(m, nn.MultiheadAttention):
+                    m.in_proj_weight.data = m.in_proj_weight.data.to(dtype)
+                    m.in_proj_bias.data = m.in_proj_bias.data.to(dtype)
+        self.heads_cast = dtype
+        return self
+
     # ------------------------------------------------------------------ helpers
     def cal_pred_logits(self, outputs):
         mask_embed = F.normalize(outputs["mask_embed"], dim=-1)
