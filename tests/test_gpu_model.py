@@ -146,8 +146,10 @@ def test_cross_scene_prefetch_does_not_change_results(dev, models):
     T = [np.diag([50.0, 50.0, 50.0, 1.0])] * 5
     vox = pipeline.default_voxelizer(device=dev)
     a = pipeline.infer_scene(g, sd, cfg, vox, T)                       # no prefetch
-    b = pipeline.infer_scene(g, sd, cfg, vox, T, next_scene=sd)        # prefetches for the next call
-    c = pipeline.infer_scene(g, sd, cfg, vox, T)                       # consumes the prefetched encoder output
+    b = pipeline.infer_scene(g, sd, cfg, vox, T, next_scene=sd, next_matrices=T)  # issues the next call's front on side streams
+    assert g._next_front is not None
+    c = pipeline.infer_scene(g, sd, cfg, vox, T)                       # consumes the prefetched front
+    assert g._next_front is None
     for x, y, z in zip(a, b, c):
         assert (x == y).float().mean().item() > 0.995 and (x == z).float().mean().item() > 0.995
 

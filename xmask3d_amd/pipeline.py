@@ -207,9 +207,11 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
     the reference's batch-1 loop, run/infer.py:428-482).  Per-view results do not depend on the grouping.
     matrices: optional list of 4x4 voxelisation transforms (otherwise drawn from np.random like the reference).
     next_scene (+ next_matrices): the scene that will be inferred next.  Its shape-dynamic front (voxelisation, sparse 3D
-    nets) is issued on a side stream and its VAE-encoder graph on another once this scene's work is enqueued (dense graph,
-    fusion, votes - the host runs ~40 ms ahead of the device there), so both overlap this scene's long static graph
-    (software pipelining across scenes); the next call picks them up."""
+    nets) is issued on a side stream and its VAE-encoder graph on another once this scene's work is enqueued (the host runs
+    ~40 ms ahead of the device there); they start when this scene's convolution-bound graph B is done and overlap its
+    latency-bound graph C (software pipelining across scenes); the next call picks them up.
+    (Measured and rejected: fusion/votes/fill on a stream of their own beside the next scene's graph B - the small kernels
+    double the duration of the convolution kernels they share the device with, tools/timeline_events.py.)"""
     voxelizer = voxelizer or default_voxelizer(cfg.voxel_size, sd.device)
     ncls = len(cfg.category_split["base_category"]) + len(cfg.category_split["novel_category"])
     votes = [torch.zeros((sd.n, ncls), dtype=torch.int32, device=sd.device) for _ in range(3 if with_ablations else 1)]
@@ -230,6 +232,7 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
             front = front or model.eval_front(batch)
             outputs = model.eval_dense(batch, front)
             outputs = model.eval_fuse(batch, front, outputs)
+            model.mark("F1")  # fusion done (timeline tracing only)
         else:
             _, outputs = model(batch)
         for s, v in enumerate(views):
@@ -239,8 +242,12 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
                 if p is not None:
                     vt.index_put_((idx, p), torch.ones_like(p, dtype=torch.int32), accumulate=True)
             seen.index_fill_(0, idx, True)  # (`seen[idx] = True` uploads the scalar: a host-blocking copy)
+    if hasattr(model, "mark"):
+        model.mark("V1")  # per-view post-processing and votes done
     fill = nearest_valid_fill(sd.points, seen)  # unseen points take the label of the nearest seen point (infer.py:682-694)
     result = [vt.argmax(1)[fill] for vt in votes]
+    if hasattr(model, "mark"):
+        model.mark("P1")  # end of this scene's post-processing (tools/timeline_events.py)
     if staged and next_scene is not None:
         # everything of this scene is enqueued behind its dense graph; the host is free to issue the next scene's front
         fs = model.front_stream()

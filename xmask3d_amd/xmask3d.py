@@ -180,12 +180,17 @@ class XMASK3d(nn.Module):
         images = self.backbone.prepare(self.normalize_images(img))
         return self.backbone.feature_extractor.ldm_extractor.encode(images)
 
-    def encode_2d(self, img, imp_condition_input, encoded=None, fork_stream=None):
-        """img (B,3,H,W) 0..255 -> decoder outputs + mask-CLIP embeddings."""
-        dev = imp_condition_input.device
-        img = img.to(dev).float()
-        images = self.normalize_images(img)
-        feature = self.backbone(images, imp_condition_input, encoded, fork_stream)
+    def dense_features(self, img, imp_condition_input, encoded=None, fork_stream=None):
+        """First half of the dense branch (rows a8-a12): SD feature extractor + projections.  Convolution-bound: fills the
+        device on its own."""
+        img = img.to(imp_condition_input.device).float()
+        return self.backbone(self.normalize_images(img), imp_condition_input, encoded, fork_stream)
+
+    def dense_heads(self, img, feature):
+        """Second half (rows a13-a17): pixel decoder, transformer decoder, category logits, mask-CLIP.  Many small
+        dependent kernels: latency-bound, leaves most of the device idle."""
+        dev = img.device
+        img = img.float()
         low = self.dense_dtype != torch.float32 and self.low_precision_heads and not torch.is_grad_enabled()
         # bf16 mode: GEMMs of the pixel / transformer decoder run in bf16 too (the reference keeps them fp32; sampling in
         # xm3d_msda_forward, LayerNorm statistics and the mask logits stay f32)
@@ -194,6 +199,23 @@ class XMASK3d(nn.Module):
         for k in ("pred_masks", "mask_embed", "mask_pooled_features"):
             outputs[k] = outputs[k].float()
         outputs["images"] = img / 255.0
+        outputs.update(self.category_head(outputs))
+        outputs["pred_logits"] = self.cal_pred_logits(outputs)
+        clip_embed = self.clip_head(outputs["images"], outputs["pred_masks"])  # casts to the visual tower's dtype inside
+        outputs["mask_embed_clip"] = clip_embed["mask_embed_clip"].float()
+        return outputs
+
+    def encode_2d(self, img, imp_condition_input, encoded=None, fork_stream=None):
+        """img (B,3,H,W) 0..255 -> decoder outputs (training: + nothing else; the losses add the category head themselves)."""
+        img = img.to(imp_condition_input.device)
+        feature = self.dense_features(img, imp_condition_input, encoded, fork_stream)
+        dev = imp_condition_input.device
+        low = self.dense_dtype != torch.float32 and self.low_precision_heads and not torch.is_grad_enabled()
+        with torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=low):
+            outputs = self.sem_seg_head({k: v.float() for k, v in feature.items()})
+        for k in ("pred_masks", "mask_embed", "mask_pooled_features"):
+            outputs[k] = outputs[k].float()
+        outputs["images"] = img.float() / 255.0
         return outputs
 
     def dense_forward(self, img, cond, encoded=None, fork_stream=None):
@@ -214,9 +236,11 @@ class XMASK3d(nn.Module):
         return self
 
     def _graphs_for(self, img, cond, slot=0):
-        """Two HIP graphs per input shape and slot: A = VAE encoder (independent of the 3D branch), B = everything after it
-        with the VAE decoder forked beside the UNet inside the capture.  Slots are independent copies (own static buffers
-        and side stream) so that graph A of the next forward can run while graph B of this one is still executing."""
+        """Three HIP graphs per input shape and slot: A = VAE encoder (independent of the 3D branch); B = UNet with the VAE
+        decoder forked beside it inside the capture, then the projections (convolution-bound); C = pixel / transformer
+        decoder, category logits, mask-CLIP (latency-bound).  Slots are independent copies (own static buffers and side
+        stream) so that the next forward's front can run while this one's graph C is still executing; the event recorded
+        between B and C tells the next front when the device starts to have room."""
         key = (tuple(img.shape), img.dtype, self.dense_dtype, self.channels_last)
         if (key, slot) not in self._dense_graphs:
             for sl in range(self._graph_slots):  # capture every slot now: nothing else is in flight at the first call
@@ -227,13 +251,15 @@ class XMASK3d(nn.Module):
                     for _ in range(2 if sl == 0 else 1):  # warm-up outside capture: library algorithm selection, caches
                         self.dense_forward(s_img, s_cond, self.encode_vae(s_img))
                 torch.cuda.current_stream().wait_stream(side)
-                ga, gb = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+                ga, gb, gc = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
                 with torch.cuda.graph(ga):
                     s_enc = self.encode_vae(s_img)
                 with torch.cuda.graph(gb):
-                    s_out = self.dense_forward(s_img, s_cond, s_enc, fork)
-                self._dense_graphs[(key, sl)] = dict(ga=ga, gb=gb, img=s_img, cond=s_cond, out=s_out, side=side, b_done=None,
-                                                     keep=(s_enc, fork))
+                    s_feat = self.dense_features(s_img, s_cond, s_enc, fork)
+                with torch.cuda.graph(gc):
+                    s_out = self.dense_heads(s_img, s_feat)
+                self._dense_graphs[(key, sl)] = dict(ga=ga, gb=gb, gc=gc, img=s_img, cond=s_cond, out=s_out, side=side, b_done=None,
+                                                     keep=(s_enc, s_feat, fork))
         return self._dense_graphs[(key, slot)]
 
     def _dense_graphed(self, img, cond):
@@ -242,7 +268,16 @@ class XMASK3d(nn.Module):
         g["cond"].copy_(cond)
         g["ga"].replay()
         g["gb"].replay()
+        g["gc"].replay()
         return dict(g["out"])
+
+    def mark(self, label, stream=None):
+        """timeline tracing (tools/timeline_events.py): a timed event on `stream` when tracing is on, nothing otherwise"""
+        tr = getattr(self, "_trace", None)
+        if tr is not None:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record(stream if stream is not None else torch.cuda.current_stream())
+            tr.append((label, ev))
 
     def front_stream(self):
         """The stream `pipeline.infer_scene` runs the NEXT scene's front on (voxelisation, sparse 3D nets)."""
@@ -264,19 +299,29 @@ class XMASK3d(nn.Module):
         inds = batch_input["inds_reconstruct"].to(dev)
         graphed = self._dense_graphs is not None and not torch.is_grad_enabled()
         front = {"graphed": graphed, "img": img, "event": None}
+        tail = None
         producer = stream if stream is not None else (torch.cuda.current_stream() if img.is_cuda else None)
         if graphed:
             slot = self._slot = (getattr(self, "_slot", -1) + 1) % self._graph_slots
             g = front["g"] = self._graphs_for(img, torch.zeros(B, 768, device=dev), slot)
             g["side"].wait_stream(producer)          # the images are ready
+            tail = getattr(self, "_tail_event", None) if stream is not None else None
+            if tail is not None:                     # prefetch: hold back until the previous forward's conv-bound part is done
+                g["side"].wait_event(tail)
             if g["b_done"] is not None:
                 g["side"].wait_event(g["b_done"])    # graph B that last read this slot's buffers has finished
             with torch.cuda.stream(g["side"]):
+                self.mark("A0", g["side"])
                 g["img"].copy_(img)
                 g["ga"].replay()
+                self.mark("A1", g["side"])
         if stream is not None:
             with torch.cuda.stream(stream):
+                if tail is not None:
+                    stream.wait_event(tail)
+                self.mark("S0", stream)
                 front["pred_3d"], front["cond"], front["binary_scores"] = self.encode_3d(sinput, inds, B)
+                self.mark("S1", stream)
                 front["event"] = torch.cuda.Event()
                 front["event"].record(stream)
         else:
@@ -296,7 +341,14 @@ class XMASK3d(nn.Module):
             cur = torch.cuda.current_stream()
             g["cond"].copy_(front["cond"])
             cur.wait_stream(g["side"])
+            self.mark("B0")
             g["gb"].replay()
+            # from here on this forward is latency-bound: the next forward's front (issued on side streams) starts here
+            self._tail_event = torch.cuda.Event()
+            self._tail_event.record(cur)
+            self.mark("C0")
+            g["gc"].replay()
+            self.mark("C1")
             g["b_done"] = torch.cuda.Event()
             g["b_done"].record(cur)
             return dict(g["out"])
