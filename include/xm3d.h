@@ -206,6 +206,12 @@ int xm3d_mask_point_fuse(const uint8_t* masks, int32_t Q, int32_t Hm, int32_t Wm
  * ------------------------------------------------------------------------- */
 int xm3d_nearest_index(const float* query, int64_t n, const float* ref, int64_t m, const uint8_t* ref_valid,
                        const int64_t* counts, int64_t* out, void* stream);
+/* Segmented form (all views of a scene batch in one launch).  pts (n,3) f32 holds, per segment, its query points followed
+ * by its reference points; desc (n_seg,4) int64 ON THE DEVICE = {q_off, q_cnt, r_off, r_cnt} per segment; max_queries = a
+ * host-side upper bound of q_cnt (sizes the grid).  out[q_off+i] = r_off + index of the nearest reference point of the
+ * same segment; entries of segments without reference points, and all non-query entries, are left untouched. */
+int xm3d_nearest_index_segmented(const float* pts, const int64_t* desc, int32_t n_seg, int64_t max_queries, int64_t* out,
+                                 void* stream);
 
 #ifdef __cplusplus
 }

@@ -137,6 +137,37 @@ def test_batched_views_equal_single_view_forwards(dev, models):
                 assert _rel(out["fused_pred_feature"][s], ref["fused_pred_feature"][0]) < 5e-3
 
 
+def test_batched_fusion_and_postprocessing_equal_the_per_view_path(dev, models):
+    """fuse_eval_batched + postprocess_scene (one pass over all views) == the reference-shaped per-view loop"""
+    from xmask3d_amd import pipeline, synthetic
+
+    cfg, _, gpu = models
+    sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
+    T = [np.diag([50.0, 50.0, 50.0, 1.0])] * 5
+    vox = pipeline.default_voxelizer(device=dev)
+    with torch.no_grad():
+        batch = pipeline.build_scene_batch(sd, list(range(5)), vox, T)
+        batch["compact_outputs"] = False
+        old_batch = {k: v for k, v in batch.items() if k != "point_view"}
+        front = gpu.eval_front(batch)
+        dense = gpu.eval_dense(batch, front)          # one dense forward feeds both fusion paths
+        dense["pred_3d"] = front["pred_3d"]
+        dense["binary_pred"] = (torch.sigmoid(front["binary_scores"]) > 0.5).long()
+        new, old = dict(dense), dict(dense)
+        new.update(gpu.fuse_eval(dense, batch, front["binary_scores"]))
+        old.update(gpu.fuse_eval(dense, old_batch, front["binary_scores"]))
+        assert "fused_cat" in new and "fused_cat" not in old
+        p_new = pipeline.postprocess_scene(cfg, new, batch, True)
+        off = batch["point_offsets"]
+        for s in range(5):
+            assert torch.equal(new["final_mask_3d"][s], old["final_mask_3d"][s])
+            assert _rel(new["fused_pred_feature"][s], old["fused_pred_feature"][s]) < 1e-5
+            assert _rel(new["2d_pred_feature"][s], old["2d_pred_feature"][s]) < 1e-6
+            p_old = pipeline.postprocess_view(cfg, old, old_batch, True, s)
+            for a, b in zip(p_new, p_old):
+                assert (a[off[s]:off[s + 1]] == b).float().mean().item() > 0.999
+
+
 def test_cross_scene_prefetch_does_not_change_results(dev, models):
     from xmask3d_amd import pipeline, synthetic
 

@@ -170,6 +170,29 @@ def test_nearest_valid_fill_matches_bruteforce(dev):
 
 
 @pytest.mark.gpu
+def test_segmented_nearest_fill_equals_per_segment_fill(dev):
+    """xm3d_nearest_index_segmented (all views in one launch) == nearest_valid_fill on each view's points"""
+    from xmask3d_amd import pipeline
+
+    torch.manual_seed(2)
+    sizes = [3000, 1, 4500, 700, 2048]
+    xyz = (torch.rand(sum(sizes), 3) * 4).to(dev)
+    valid = (torch.rand(sum(sizes)) < 0.3).to(dev)
+    off = np.cumsum([0] + sizes)
+    valid[off[1]:off[2]] = False            # a one-point segment without any reference: maps to itself
+    valid[off[3]:off[4]] = True             # a segment with nothing to fill
+    seg = torch.cat([torch.full((n,), i, dtype=torch.long) for i, n in enumerate(sizes)]).to(dev)
+    got = pipeline.nearest_valid_fill_segmented(xyz, valid, seg, len(sizes), max(sizes)).cpu()
+    for i in range(len(sizes)):
+        lo, hi = int(off[i]), int(off[i + 1])
+        if i == 1:
+            assert got[lo:hi].tolist() == [lo]
+            continue
+        want = pipeline.nearest_valid_fill(xyz[lo:hi], valid[lo:hi]).cpu() + lo
+        assert torch.equal(got[lo:hi], want), f"segment {i}"
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
 def test_bilinear_down_bit_identical_on_device(dev, dtype):
     import torch.nn.functional as F

@@ -56,9 +56,71 @@ __global__ __launch_bounds__(256) void k_nearest(const float* __restrict__ q, in
     if (i < n) out[i] = besti;
 }
 
+// Segmented form for the per-view hole filling of a whole scene batch in one launch: `pts` holds, for every segment
+// (view), its query points followed by its reference points; desc[s] = {q_off, q_cnt, r_off, r_cnt} lives on the device
+// (the counts come out of a device-side partition: no host round trip).  blockIdx.y = segment, blockIdx.x = 256-query
+// slab; out[q_off + i] = r_off + (index of the nearest reference of the same segment); segments without references
+// leave their queries untouched (the caller pre-fills out with the identity).
+__global__ __launch_bounds__(256) void k_nearest_seg(const float* __restrict__ pts, const int64_t* __restrict__ desc,
+                                                     int64_t* __restrict__ out) {
+    __shared__ float4 tile[NN_TILE];
+    const int64_t* d4 = desc + 4 * int64_t(blockIdx.y);
+    const int64_t q_off = d4[0], n = d4[1], r_off = d4[2], m = d4[3];
+    if (int64_t(blockIdx.x) * blockDim.x >= n || m <= 0) return;
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    float qx = 0.f, qy = 0.f, qz = 0.f;
+    if (i < n) {
+        const float* p = pts + 3 * (q_off + i);
+        qx = p[0];
+        qy = p[1];
+        qz = p[2];
+    }
+    const float* r = pts + 3 * r_off;
+    float best = INFINITY;
+    int64_t besti = 0;
+    for (int64_t t0 = 0; t0 < m; t0 += NN_TILE) {
+        const int cnt = int((m - t0 < NN_TILE) ? m - t0 : NN_TILE);
+        __syncthreads();
+        for (int j = threadIdx.x; j < cnt; j += 256) {
+            const float* p = r + 3 * (t0 + j);
+            tile[j] = make_float4(p[0], p[1], p[2], 0.f);
+        }
+        __syncthreads();
+        float tb = best;
+        int tj = -1;
+#pragma unroll 8
+        for (int j = 0; j < cnt; ++j) {
+            const float4 p = tile[j];
+            const float dx = qx - p.x, dy = qy - p.y, dz = qz - p.z;
+            const float d = fmaf(dz, dz, fmaf(dy, dy, dx * dx));
+            if (d < tb) {
+                tb = d;
+                tj = j;
+            }
+        }
+        if (tj >= 0) {
+            best = tb;
+            besti = t0 + tj;
+        }
+    }
+    if (i < n) out[q_off + i] = r_off + besti;
+}
+
 }  // namespace xm3d
 
 using namespace xm3d;
+
+extern "C" int xm3d_nearest_index_segmented(const float* pts, const int64_t* desc, int32_t n_seg, int64_t max_queries, int64_t* out,
+                                            void* stream) {
+    XM3D_REQUIRE(n_seg >= 0 && n_seg <= 65535 && max_queries >= 0, "nearest_index_segmented: bad sizes n_seg=%d max_queries=%lld", n_seg,
+                 (long long)max_queries);
+    if (n_seg == 0 || max_queries == 0) return XM3D_OK;
+    XM3D_REQUIRE(pts && desc && out, "nearest_index_segmented: null pointer");
+    hipLaunchKernelGGL(k_nearest_seg, dim3(unsigned((max_queries + 255) / 256), unsigned(n_seg)), dim3(256), 0, as_stream(stream), pts, desc,
+                       out);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
 
 extern "C" int xm3d_nearest_index(const float* query, int64_t n, const float* ref, int64_t m, const uint8_t* ref_valid,
                                   const int64_t* counts, int64_t* out, void* stream) {

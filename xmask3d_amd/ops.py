@@ -406,6 +406,19 @@ def mask_point_fuse(masks_u8, x_label, y_label, embed):
 
 
 # ---------------------------------------------------------------- nearest neighbour
+def nearest_index_segmented(pts, desc, max_queries, out):
+    """pts (n,3) f32 laid out per segment as [queries | references]; desc (S,4) i64 device {q_off,q_cnt,r_off,r_cnt};
+    out (n,) i64 pre-filled by the caller: out[q_off+i] <- r_off + nearest reference of the same segment."""
+    _req(pts, torch.float32, "pts", 2)
+    _req(desc, torch.int64, "desc", 2)
+    _req(out, torch.int64, "out", 1)
+    if pts.shape[1] != 3 or desc.shape[1] != 4 or out.numel() != pts.shape[0]:
+        raise RuntimeError("nearest_index_segmented: pts (n,3), desc (S,4), out (n,) expected")
+    check(lib().xm3d_nearest_index_segmented(_ptr(pts), _ptr(desc), desc.shape[0], int(max_queries), _ptr(out), _stream()),
+          "xm3d_nearest_index_segmented")
+    return out
+
+
 def nearest_index(query, ref, ref_valid=None, counts=None):
     """(n,3) f32, (m,3) f32 -> (n,) i64 index of the nearest reference point (exact, lowest index on ties).
     ref_valid (m,) uint8/bool: only reference points with a non-zero flag are considered.

@@ -49,6 +49,11 @@ class SceneOnDevice:
                 img=torch.from_numpy(scene.images[v]).permute(2, 0, 1)[None].contiguous().to(device),
                 caption=scene.captions[v]))
         self.img_all = torch.cat([v["img"] for v in self.views])  # all views as one batch (stable storage: prefetch key)
+        # all-views batch: concatenated per-point tables, built once (per-call torch.cat / fills are launches on the hot path)
+        self.idx_all = torch.cat([v["idx"] for v in self.views])
+        self.x_all = torch.cat([v["x"] for v in self.views])
+        self.y_all = torch.cat([v["y"] for v in self.views])
+        self.view_all = torch.cat([torch.full((v["idx"].shape[0],), i, dtype=torch.long, device=device) for i, v in enumerate(self.views)])
 
 
 def build_view_batch(sd: SceneOnDevice, view: int, voxelizer: Voxelizer, matrix=None):
@@ -82,10 +87,15 @@ def build_scene_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, matrices=N
         ori.append(torch.cat([torch.full((pts.shape[0], 1), float(b), device=sd.device), pts.float()], 1))
         xs.append(vw["x"]); ys.append(vw["y"]); imgs.append(vw["img"]); caps.append(vw["caption"])
     coords = torch.cat(coords).contiguous()
-    img = sd.img_all if list(views) == list(range(len(sd.views))) else torch.cat(imgs)
-    return {"sinput": ME.SparseTensor(torch.cat(feats).contiguous(), coords), "img": img, "x_label": torch.cat(xs),
-            "y_label": torch.cat(ys), "inds_reconstruct": torch.cat(inv), "ori_coords": torch.cat(ori), "captions": tuple(caps),
-            "coords": coords, "label_2d": None, "labels_3d": None, "use_pure_3d": False, "point_offsets": offsets}
+    if list(views) == list(range(len(sd.views))):
+        img, x_all, y_all, view_all = sd.img_all, sd.x_all, sd.y_all, sd.view_all
+    else:
+        img, x_all, y_all = torch.cat(imgs), torch.cat(xs), torch.cat(ys)
+        view_all = torch.cat([torch.full((offsets[b + 1] - offsets[b],), b, dtype=torch.long, device=sd.device) for b in range(len(views))])
+    return {"sinput": ME.SparseTensor(torch.cat(feats).contiguous(), coords), "img": img, "x_label": x_all,
+            "y_label": y_all, "inds_reconstruct": torch.cat(inv), "ori_coords": torch.cat(ori), "captions": tuple(caps),
+            "coords": coords, "label_2d": None, "labels_3d": None, "use_pure_3d": False, "point_offsets": offsets,
+            "point_view": view_all}
 
 
 def build_train_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, seed=0, n_classes=15, ignore=(19, 20)):
@@ -139,6 +149,21 @@ def nearest_valid_fill(xyz: torch.Tensor, valid: torch.Tensor):
     live = torch.arange(n, device=xyz.device) < (n - n_valid)
     # scatter the answers of the live queries back; every other point keeps its own index
     return fill.scatter(0, q_order, torch.where(live, r_order[nn], q_order))
+
+
+def nearest_valid_fill_segmented(xyz, valid, seg, n_seg, max_seg_points):
+    """nearest_valid_fill inside every segment (view) of a concatenated point set, one launch: xyz (n,3), valid (n,) bool,
+    seg (n,) long segment id per point, max_seg_points = host-side bound of a segment's size.  Same result as calling
+    nearest_valid_fill per segment (stable partition -> lowest original index wins ties); no host synchronisation."""
+    n = xyz.shape[0]
+    key = seg * 2 + valid.long()                      # per segment: invalid points (queries) first, valid ones (references) after
+    order = torch.argsort(key, stable=True)
+    cnt = torch.zeros(2 * n_seg, dtype=torch.int64, device=xyz.device).index_add_(0, key, torch.ones_like(key))
+    off = torch.cumsum(cnt, 0) - cnt
+    desc = torch.stack([off[0::2], cnt[0::2], off[1::2], cnt[1::2]], 1).contiguous()
+    out = torch.arange(n, device=xyz.device)          # identity for reference points and for segments without references
+    ops.nearest_index_segmented(xyz.float()[order].contiguous(), desc, max_seg_points, out)
+    return torch.empty_like(out).scatter_(0, order, order[out])
 
 
 _CONSTS = {}
@@ -199,6 +224,37 @@ def postprocess_view(cfg, outputs, batch, with_ablations=True, s=0):
     return pred, pred2d, pred3d
 
 
+def postprocess_scene(cfg, outputs, batch, with_ablations=True):
+    """postprocess_view for all batch entries at once, on the concatenated tensors of XMASK3d.fuse_eval_batched:
+    -> class id per visible point (all entries back to back) for the fused / 2D-only / 3D-only predictions."""
+    text = F.normalize(outputs["text_embed"], dim=-1)
+    base, novel, overlap = _class_consts(cfg, text.shape[0], text.device)
+    scale = outputs["logit_scale"]
+    vid = batch["point_view"]
+    offsets = batch["point_offsets"]
+    binary_pred = outputs["binary_pred"]
+    probs = (scale * (F.normalize(outputs["fused_cat"], dim=-1) @ text.t())).softmax(dim=-1)
+    open_p = (scale * (F.normalize(outputs["open_embedding_all"], dim=-1) @ text.t())).softmax(dim=-1)   # (B, Q, C)
+    masks = outputs["mask_3d_cat"]                     # (Np, Q), pixel-disjoint: at most one query per point
+    covered = masks.any(1)
+    po = open_p[vid, masks.to(torch.uint8).argmax(1)]
+    b = (probs ** cfg.base_ratio * po ** (1 - cfg.base_ratio)).log() * overlap
+    n = (probs ** cfg.novel_ratio * po ** (1 - cfg.novel_ratio)).log() * (1 - overlap)
+    probs = torch.where(covered[:, None], b + n, probs)
+    pred = _gate(probs, binary_pred, base, novel).argmax(1)
+    if not with_ablations:
+        return pred, None, None
+    f2d = outputs["feat2d_cat"]
+    empty = f2d.sum(1) == 0
+    n_seg = len(offsets) - 1
+    fill = nearest_valid_fill_segmented(batch["ori_coords"][:, 1:], ~empty, vid, n_seg,
+                                        max(offsets[i + 1] - offsets[i] for i in range(n_seg)))
+    f2d = f2d[fill]  # points without a 2D feature take the nearest covered point's of the same view (infer.py:523-553)
+    pred2d = _gate(scale * (F.normalize(f2d, dim=-1) @ text.t()), binary_pred, base, novel).argmax(1)
+    pred3d = _gate(scale * (F.normalize(outputs["pure3d_cat"], dim=-1) @ text.t()), binary_pred, base, novel).argmax(1)
+    return pred, pred2d, pred3d
+
+
 @torch.no_grad()
 def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, with_ablations=True, views_per_batch=None,
                 next_scene: SceneOnDevice | None = None, next_matrices=None):
@@ -235,6 +291,14 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
             model.mark("F1")  # fusion done (timeline tracing only)
         else:
             _, outputs = model(batch)
+        if "fused_cat" in outputs:  # batched fusion ran: post-process and vote for all views of the batch in one go
+            preds = postprocess_scene(cfg, outputs, batch, with_ablations)
+            idx = sd.idx_all if len(views) == nv else torch.cat([sd.views[v]["idx"] for v in views])
+            for vt, p in zip(votes, preds):
+                if p is not None:
+                    vt.index_put_((idx, p), torch.ones_like(p, dtype=torch.int32), accumulate=True)
+            seen.index_fill_(0, idx, True)
+            continue
         for s, v in enumerate(views):
             preds = postprocess_view(cfg, outputs, batch, with_ablations, s)
             idx = sd.views[v]["idx"]

@@ -369,6 +369,66 @@ class XMASK3d(nn.Module):
         front = self.eval_front(batch_input)
         return None, self.eval_fuse(batch_input, front, self.eval_dense(batch_input, front))
 
+    def fuse_eval_batched(self, outputs, batch_input, binary_scores):
+        """fuse_eval over all batch entries at once: the same arithmetic as the per-entry loop (models/xmask3d.py:326-487),
+        organised per point (Np_total, Q) with the entry index of each point (`point_view`) instead of per entry (Q, Np):
+        ~25 launches for the whole batch instead of ~40 per entry.  Needs `point_offsets` (host) and `point_view` (device);
+        keeps all Q mask rows (no host synchronisation).  Besides the reference's per-entry lists it returns the
+        concatenated tensors (`*_cat`) that pipeline.postprocess_scene consumes."""
+        cfg = self.cfg
+        dev = outputs["pred_3d"].device
+        masks = F.interpolate(outputs["pred_masks"], size=tuple(cfg.mask_shape), mode="bilinear", align_corners=False)
+        B, Q = masks.shape[:2]
+        offsets = batch_input["point_offsets"]
+        sizes = [offsets[i + 1] - offsets[i] for i in range(B)]
+        vid = batch_input["point_view"]
+        x, y = batch_input["x_label"].to(dev), batch_input["y_label"].to(dev)
+        cs = cfg.category_split
+        base_cat, novel_cat = list(cs["base_category"]), list(cs["novel_category"])
+        num_classes = cfg.test_ignore_label[0]
+        ck = (str(dev), outputs["pred_logits"].shape[-1])
+        if getattr(self, "_fuse_cols", (None,))[0] != ck:  # built once: a per-call host->device copy would stall the host
+            bc, nc = torch.zeros(ck[1], dtype=torch.bool), torch.zeros(ck[1], dtype=torch.bool)
+            bc[base_cat + [num_classes]] = True
+            nc[novel_cat] = True
+            self._fuse_cols = (ck, bc.to(dev), nc.to(dev))
+        base_cols, novel_cols = self._fuse_cols[1:]
+        p3d = outputs["pred_3d"]
+        m3d_full = masks[vid, :, x, y].sigmoid() > 0.5                       # (Np, Q): mask q covers point p
+        cover = m3d_full.float()
+        weighted = torch.sigmoid(binary_scores).view(-1, 1) * cover
+        # per-entry sums over the entry's own contiguous point range (deterministic reductions, no float atomics)
+        cnt_q = torch.stack([cover[offsets[i]:offsets[i + 1]].sum(0) for i in range(B)])        # (B, Q)
+        num_q = torch.stack([weighted[offsets[i]:offsets[i + 1]].sum(0) for i in range(B)])
+        keep_full = cnt_q > 0
+        is_base = (num_q / (cnt_q + 1e-10) > cfg.binary_2d_thresh).unsqueeze(-1)
+        cls = outputs["pred_logits"]
+        modified = torch.where(is_base, cls.masked_fill(novel_cols, -1e10), cls.masked_fill(base_cols, -1e10))
+        scores = F.softmax(modified, dim=-1).max(-1)[0]                        # (B, Q)
+        mask_pred = masks.sigmoid()
+        keep = keep_full & (scores > cfg.scores_keep_thresh)
+        # queries not kept must not win the per-pixel arg-max: give them score -1 (kept scores are > 0)
+        prob = torch.where(keep, scores, torch.full_like(scores, -1.0)).view(B, Q, 1, 1) * mask_pred
+        ids = prob.argmax(1)
+        qidx = torch.arange(Q, device=dev).view(1, -1, 1, 1)
+        final = (ids[:, None] == qidx) & (mask_pred >= 0.5) & keep.view(B, Q, 1, 1)
+        final_u8 = final.to(torch.uint8)
+        emb = outputs["mask_embed"].float()
+        f2d_l, cnt_l = [], []
+        for i in range(B):
+            sel = slice(offsets[i], offsets[i + 1])
+            f, c = ops.mask_point_fuse(final_u8[i], x[sel], y[sel], emb[i].contiguous())
+            f2d_l.append(f), cnt_l.append(c)
+        feat2d, cnt = torch.cat(f2d_l), torch.cat(cnt_l)
+        mask_3d = final[vid, :, x, y]                                          # (Np, Q)
+        fused = torch.where((cnt >= 1).view(-1, 1), self.criterion.fuser(feat2d, p3d), p3d)
+        pure3d = self.criterion.fc1(p3d)
+        emb_open = outputs["mask_embed_clip"]
+        return {"fused_pred_feature": list(fused.split(sizes)), "2d_pred_feature": list(feat2d.split(sizes)),
+                "pure3d_pred_feature": list(pure3d.split(sizes)), "final_mask_3d": [m.t() for m in mask_3d.split(sizes)],
+                "final_pred_open_embedding": [emb_open[i] for i in range(B)],
+                "fused_cat": fused, "feat2d_cat": feat2d, "pure3d_cat": pure3d, "mask_3d_cat": mask_3d, "open_embedding_all": emb_open}
+
     def forward_train(self, batch_input):
         """models/xmask3d.py:182-305: Hungarian-matched mask losses (main + 9 aux), 3D CE losses on fused / pure-3D point
         features, caption cosine losses, binary base/novel loss; returns weighted losses."""
@@ -425,6 +485,9 @@ class XMASK3d(nn.Module):
         all-False rows for the queries that were dropped (same votes downstream)."""
         cfg = self.cfg
         dev = outputs["pred_3d"].device
+        if batch_input.get("point_offsets") is not None and not batch_input.get("compact_outputs", True) \
+                and batch_input.get("point_view") is not None:
+            return self.fuse_eval_batched(outputs, batch_input, binary_scores)
         masks = F.interpolate(outputs["pred_masks"], size=tuple(cfg.mask_shape), mode="bilinear", align_corners=False)
         ori_coords = batch_input["ori_coords"].to(dev)
         x_all, y_all = batch_input["x_label"].to(dev), batch_input["y_label"].to(dev)
