@@ -100,7 +100,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views-per-batch", type=int, default=0, help="views per forward (0 = all views of the scene; 1 = reference loop)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find through the shipped find-db)")
-    ap.add_argument("--channels-last", action="store_true", help="NHWC activations in the frozen conv nets")
+    ap.add_argument("--nchw", action="store_true", help="keep NCHW activations in the frozen conv nets (default: channels-last)")
     ap.add_argument("--no-graph", action="store_true", help="launch the dense branch eagerly instead of replaying a HIP graph")
     ap.add_argument("--faithful-dead-compute", action="store_true", help="also run what the reference computes and discards")
     ap.add_argument("--roofline-only", action="store_true",
@@ -157,7 +157,7 @@ def main():
     model = copy.deepcopy(cpu_model).to(dev).eval()
     dense_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model.set_dense_dtype(dense_dtype)
-    if args.channels_last:
+    if not args.nchw:
         model.set_channels_last(True)
     if dense_dtype == torch.bfloat16:
         model.cast_head_weights()
@@ -265,10 +265,12 @@ def main():
     out = {
         "metric": "ScanNet scenes/sec (infer)", "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype + " (frozen SD/CLIP nets) + f32 (sparse 3D, deformable attention, heads)", "data": "synthetic",
+        "dtype": args.dtype + " (frozen SD/CLIP nets, decoder GEMMs) + f32 (sparse 3D, deformable attention, statistics, logits)", "data": "synthetic",
         "config": {"workload": "ScanNet B15N4 inference, synthetic scene S1 (119963 pts, 5 views 240x320->512x512), "
                                f"{vb} views per forward, seeded random weights", "views_per_scene": n_views, "parallelism": f"dp{world} (scene level, no collective)",
-                   "dead_compute": "as reference" if args.faithful_dead_compute else "pruned (SURVEY F7)"},
+                   "dead_compute": "as reference" if args.faithful_dead_compute else "pruned (SURVEY F7)",
+                   "layout": "NCHW" if args.nchw else "channels-last (NHWC) frozen nets",
+                   "schedule": "eager launches" if args.no_graph else "3 HIP graphs per scene + 2-scene software pipeline on side streams"},
         "roofline": roofline, "roofline_dense_stage": roofline_stage, "cpu_baseline": cpu_baseline,
     }
     print(json.dumps(out))

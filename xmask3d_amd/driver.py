@@ -115,12 +115,18 @@ def train(cfg, epochs=1, iters_per_epoch=4, views_per_gpu=2, save_path=None, res
 def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, log=print):
     """-> dict of open-vocabulary scores for the fused / 2D / 3D predictions (infer.py:696-911 bookkeeping)."""
     rank, world, dev = setup_distributed(cfg)
-    if model is None:
+    own = model is None
+    if own:
         torch.manual_seed(cfg.manual_seed)
         model = XMASK3d(cfg).to(dev)
         if resume:
             ckpt_io.load_checkpoint(resume, model, eval=True, map_location=dev)
-    model = (model.module if hasattr(model, "module") else model).eval().set_dense_dtype(dense_dtype).enable_dense_graph()
+    model = (model.module if hasattr(model, "module") else model).eval().set_dense_dtype(dense_dtype)
+    if dense_dtype == torch.bfloat16 and dev.type == "cuda":
+        model.set_channels_last(True)   # NHWC convolutions + folded GroupNorm / residual kernels
+        if own:                         # a model handed in may be trained further: keep its fp32 head weights
+            model.cast_head_weights()
+    model.enable_dense_graph()
     K = cfg.test_classes
     names = ("fused", "2d", "3d")
     acc = torch.zeros(3, 3, K, device=dev)
