@@ -138,6 +138,20 @@ int xm3d_spconv_bwd_weight(const float* in, int64_t n_in, int32_t cin, const flo
 int xm3d_bn_stats(const float* x, int64_t n, int32_t c, double* sum_sumsq, void* stream);
 int xm3d_affine_act(const float* x, int64_t n, int32_t c, const float* scale, const float* shift,
                     const float* residual, int32_t relu, float* out, void* stream);
+/* Training-mode BatchNorm (ME.MinkowskiBatchNorm / MinkowskiSyncBatchNorm in train(), mink_unet.py:51-116; backward reached
+ * from loss.backward(), run/train.py:537).  packed = [sum(c), sumsq(c), count] f64 (xm3d_bn_stats output, all-reduced over
+ * the ranks for SyncBatchNorm); total >= 0 overrides packed[2c] (single rank: the host knows the row count).
+ * -> mean, invstd, scale = invstd*w, shift = -mean*invstd*w + b (all f32 (c)), total_out (1); momentum >= 0 also updates
+ * running_mean / running_var (unbiased variance) / num_batches in place. */
+int xm3d_bn_finalize(const double* packed, int32_t c, double total, const float* weight, const float* bias, float eps,
+                     float momentum, float* running_mean, float* running_var, int64_t* num_batches, float* mean, float* invstd,
+                     float* scale, float* shift, float* total_out, void* stream);
+/* sums = [sum_r gy, sum_r gy*xhat] f64 (2c) with xhat = (x-mean)*invstd (all-reduce it for SyncBatchNorm), then
+ * gx = w*invstd*(gy - sum_dy/total - xhat*sum_dy_xhat/total), gw = sum_dy_xhat, gb = sum_dy (gw/gb may be NULL). */
+int xm3d_bn_bwd_reduce(const float* gy, const float* x, int64_t n, int32_t c, const float* mean, const float* invstd, double* sums,
+                       void* stream);
+int xm3d_bn_bwd_apply(const float* gy, const float* x, int64_t n, int32_t c, const float* mean, const float* invstd,
+                      const float* weight, const double* sums, const float* total, float* gx, float* gw, float* gb, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Fused GroupNorm (+SiLU) over NCHW activations (replaces nn.GroupNorm(32,C) [+ x*sigmoid(x)] inside the SD

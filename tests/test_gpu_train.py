@@ -60,14 +60,25 @@ def test_batchnorm_function_matches_torch(dev):
     x = (torch.randn(5000, 64) * 2 + 0.5)
     w, b, gy = torch.rand(64) + 0.5, torch.randn(64), torch.randn(5000, 64)
     xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-    ref = torch.nn.functional.batch_norm(xr, None, None, wr, br, True, 0.1, 1e-5)
+    rm_ref, rv_ref = torch.zeros(64), torch.ones(64)
+    ref = torch.nn.functional.batch_norm(xr, rm_ref, rv_ref, wr, br, True, 0.1, 1e-5)
     ref.backward(gy)
     xd, wd, bd = (t.to(dev).requires_grad_(True) for t in (x, w, b))
-    y, mean, var, n = _BatchNormFn.apply(xd, wd, bd, 1e-5, None)
+    rm, rv, nb = torch.zeros(64, device=dev), torch.ones(64, device=dev), torch.zeros((), dtype=torch.int64, device=dev)
+    y = _BatchNormFn.apply(xd, wd, bd, 1e-5, None, rm, rv, nb, 0.1)
     y.backward(gy.to(dev))
     assert _rel(y, ref.detach()) < 1e-5 and _rel(xd.grad, xr.grad) < 1e-4
     assert _rel(wd.grad, wr.grad) < 1e-4 and _rel(bd.grad, br.grad) < 1e-4
-    assert float(n) == 5000
+    # running buffers follow torch's update rule (unbiased variance), the batch counter advances
+    assert _rel(rm, rm_ref) < 1e-5 and _rel(rv, rv_ref) < 1e-5 and int(nb) == 1
+    # no affine parameters, no running buffers
+    x2 = x.to(dev).requires_grad_(True)
+    y2 = _BatchNormFn.apply(x2, None, None, 1e-5, None, None, None, None, None)
+    y2.backward(gy.to(dev))
+    xr2 = x.clone().requires_grad_(True)
+    ref2 = torch.nn.functional.batch_norm(xr2, None, None, None, None, True, 0.1, 1e-5)
+    ref2.backward(gy)
+    assert _rel(y2, ref2.detach()) < 1e-5 and _rel(x2.grad, xr2.grad) < 1e-4
 
 
 def test_minkunet_training_backward_matches_oracle(dev):

@@ -27,7 +27,7 @@ core = model.module if world > 1 else model
 # two parameter groups as run/train.py:152-169
 p3d = [p for n, p in core.named_parameters() if p.requires_grad and ("pc_decoder" in n or "pc_binary_head" in n)]
 rest = [p for n, p in core.named_parameters() if p.requires_grad and not ("pc_decoder" in n or "pc_binary_head" in n)]
-opt = torch.optim.AdamW([{"params": p3d, "lr": cfg.lr_3d}, {"params": rest, "lr": cfg.lr_others}])
+opt = torch.optim.AdamW([{"params": p3d, "lr": cfg.lr_3d}, {"params": rest, "lr": cfg.lr_others}], fused=True)
 sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
 vox = pipeline.default_voxelizer(device=dev)
 np.random.seed(cfg.manual_seed + rank)

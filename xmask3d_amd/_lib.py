@@ -43,6 +43,9 @@ _SIGS = {
     "xm3d_spconv_bwd_weight": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i64, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "xm3d_bn_stats": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp]),
     "xm3d_affine_act": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "xm3d_bn_finalize": (ctypes.c_int, [c_vp, c_i32, ctypes.c_double, c_vp, c_vp, ctypes.c_float, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
+    "xm3d_bn_bwd_reduce": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "xm3d_bn_bwd_apply": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_group_norm": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp, c_vp]),
     "xm3d_group_norm_nhwc": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp, c_vp]),
     "xm3d_bias_residual_nhwc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),

@@ -91,6 +91,14 @@ class HungarianMatcher(nn.Module):
             C = self.cost_mask * batch_sigmoid_ce_loss(out, tgt) + self.cost_class * cost_class + self.cost_dice * batch_dice_loss(out, tgt)
             i, j = linear_sum_assignment(C.reshape(num_queries, -1).cpu())
             indices.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
+        dev = outputs["pred_logits"].device
+        if dev.type != "cpu" and indices:
+            # one upload for the whole batch: the losses index device tensors with these, and every index tensor left on the
+            # host would cost its own blocking host->device copy (seven per decoder layer)
+            sizes = [len(i) for i, _ in indices]
+            flat = torch.cat([torch.cat(p) for p in indices]).to(dev)
+            parts = flat.split([2 * n for n in sizes])
+            indices = [(p[:n], p[n:]) for p, n in zip(parts, sizes)]
         return indices
 
 
@@ -220,19 +228,24 @@ class Criterion(nn.Module):
             keep = mask_3d.sum(1) >= 10
             mask_k, clip_k, mask_3d = mask[keep], clip_emb[keep], mask_3d[keep]
             last_mask_embed = mask_embed[keep]
+            # per-mask statistics for all kept masks at once, ONE device->host copy (the reference's per-mask python loop,
+            # criterion.py:186-215, costs two host syncs per mask)
+            bg = binary_gt.view(1, -1)
+            tot = mask_3d.sum(1)
+            n_novel = (mask_3d & bg.eq(0)).sum(1)
+            n_base_ = (mask_3d & bg.eq(1)).sum(1)
+            p = mask_k.sigmoid().flatten(1)
+            hi = p > 0.5
+            conf = (p * hi).sum(1) / hi.sum(1)  # mean of p[p > 0.5]; NaN for an empty set, like .mean() of nothing
+            st = torch.stack([tot.double(), n_novel.double(), n_base_.double(), conf.double()]).cpu().tolist()
             novel, base = [], []
-            for i, (m3, m2) in enumerate(zip(mask_3d, mask_k)):
-                g = binary_gt[m3]
-                novel_num = int(g.eq(0).sum())
-                base_num = len(g) - novel_num
-                base_num_ = int(g.eq(1).sum())
-                novel_num_ = len(g) - base_num_
-                p = m2.sigmoid()
-                conf = p[p > 0.5].mean()
+            for i in range(mask_3d.shape[0]):
+                novel_num, base_num_ = int(st[1][i]), int(st[2][i])
+                base_num, novel_num_ = int(st[0][i]) - novel_num, int(st[0][i]) - base_num_
                 if novel_num > 1.8 * base_num and novel_num > 10:
-                    novel.append((i, conf))
+                    novel.append((i, st[3][i]))
                 elif base_num_ > 20 * novel_num_ and base_num_ > 150:
-                    base.append((i, conf))
+                    base.append((i, st[3][i]))
             if novel or base:
                 pick = [i for i, _ in sorted(novel, key=lambda t: t[1], reverse=True)][:4]
                 pick += [i for i, _ in sorted(base, key=lambda t: t[1], reverse=True)][:1]

@@ -27,6 +27,7 @@ import types
 
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from . import ops
 
@@ -73,7 +74,7 @@ def sync_moments(s, ss, n, group=None):
     Pure tensor math so the reduction logic is testable on CPU with gloo."""
     import torch.distributed as dist
 
-    packed = torch.cat([s.double(), ss.double(), torch.as_tensor([float(n)], dtype=torch.float64, device=s.device)])
+    packed = torch.cat([s.double(), ss.double(), torch.full((1,), float(n), dtype=torch.float64, device=s.device)])  # (a fill, not a host->device upload)
     if group is not None:
         dist.all_reduce(packed, group=None if group is True else group)
     c = s.numel()
@@ -84,40 +85,39 @@ def sync_moments(s, ss, n, group=None):
 
 
 class _BatchNormFn(torch.autograd.Function):
-    """training-mode BatchNorm over rows with optional cross-rank statistics (MinkowskiBatchNorm / SyncBatchNorm)."""
+    """training-mode BatchNorm over rows with optional cross-rank statistics (MinkowskiBatchNorm / SyncBatchNorm):
+    statistics pass, one per-channel kernel (mean / invstd / affine terms / running buffers), affine pass; backward =
+    one reduction + one elementwise kernel.  The counts stay on the device: no host synchronisation per layer."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, eps, group):
-        s, ss = ops.bn_stats(x)
-        mean, var, total = sync_moments(s, ss, x.shape[0], group)
-        invstd = torch.rsqrt(var + eps)
-        w = weight.double() if weight is not None else torch.ones_like(invstd)
-        scale = (invstd * w).float()
-        shift = (-mean * invstd * w).float()
-        if bias is not None:
-            shift = shift + bias
-        y = ops.affine_act(x, scale.contiguous(), shift.contiguous())
-        ctx.save_for_backward(x, weight, mean.float(), invstd.float())
-        ctx.group, ctx.total = group, float(total)
-        ctx.mark_non_differentiable(mean, var, total)
-        return y, mean, var, total
-
-    @staticmethod
-    def backward(ctx, gy, _gm, _gv, _gt):
+    def forward(ctx, x, weight, bias, eps, group, running_mean, running_var, num_batches, momentum):
         import torch.distributed as dist
 
-        x, weight, mean, invstd = ctx.saved_tensors
-        xhat = (x - mean) * invstd
-        sum_dy, sum_dy_xhat = gy.sum(0), (gy * xhat).sum(0)
-        gw = sum_dy_xhat if weight is not None else None
-        gb = sum_dy
+        c = x.shape[1]
+        packed = ops.bn_stats_packed(x)
+        total = float(x.shape[0])
+        if group is not None:
+            packed[2 * c:].fill_(total)
+            dist.all_reduce(packed, group=None if group is True else group)
+            total = -1.0  # read the all-reduced count from the buffer
+        mean, invstd, scale, shift, tot = ops.bn_finalize(packed, c, total, weight, bias, eps, momentum, running_mean, running_var,
+                                                          num_batches)
+        y = ops.affine_act(x, scale, shift)
+        ctx.save_for_backward(x, weight, mean, invstd, tot)
+        ctx.group, ctx.has_bias = group, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        import torch.distributed as dist
+
+        x, weight, mean, invstd, tot = ctx.saved_tensors
+        gy = gy.contiguous()
+        sums = ops.bn_bwd_reduce(gy, x, mean, invstd)
         if ctx.group is not None:
-            red = torch.cat([sum_dy, sum_dy_xhat])
-            dist.all_reduce(red, group=None if ctx.group is True else ctx.group)
-            sum_dy, sum_dy_xhat = red[: sum_dy.numel()], red[sum_dy.numel():]
-        w = weight if weight is not None else torch.ones_like(invstd)
-        gx = (w * invstd) * (gy - sum_dy / ctx.total - xhat * (sum_dy_xhat / ctx.total))
-        return gx, gw, gb, None, None
+            dist.all_reduce(sums, group=None if ctx.group is True else ctx.group)
+        gx, gw, gb = ops.bn_bwd_apply(gy, x, mean, invstd, weight, sums, tot, need_wb=weight is not None or ctx.has_bias)
+        return gx, (gw if weight is not None else None), (gb if ctx.has_bias else None), None, None, None, None, None, None
 
 
 # ----------------------------------------------------------------------------- tensors
@@ -361,9 +361,20 @@ class MinkowskiBatchNorm(nn.Module):
     def _batch_stats_forward(self, x, group):
         bn = self.bn
         feats = x.F
-        if torch.is_grad_enabled():
-            y, mean, var, total = _BatchNormFn.apply(feats, bn.weight if bn.affine else None, bn.bias if bn.affine else None,
-                                                     bn.eps, group)
+        if torch.is_grad_enabled() and (bn.momentum is not None or not bn.track_running_stats):
+            track = self.training and bn.track_running_stats
+            y = _BatchNormFn.apply(feats, bn.weight if bn.affine else None, bn.bias if bn.affine else None, bn.eps, group,
+                                   bn.running_mean if track else None, bn.running_var if track else None,
+                                   bn.num_batches_tracked if track else None, bn.momentum if track else None)
+            return x._like(y)
+        elif torch.is_grad_enabled():  # cumulative-average running statistics (momentum=None): torch ops
+            feats_ = feats
+            s, ss = ops.bn_stats(feats_.detach())
+            mean, var, total = sync_moments(s, ss, feats.shape[0], group)
+            y = F.batch_norm(feats, None, None, bn.weight if bn.affine else None, bn.bias if bn.affine else None, True, 0.0, bn.eps) \
+                if group is None else None
+            if y is None:
+                raise NotImplementedError("SyncBatchNorm with momentum=None is not supported")
             out = x._like(y)
         else:
             s, ss = ops.bn_stats(feats)

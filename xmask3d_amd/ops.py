@@ -280,6 +280,44 @@ def bn_stats(x):
     return s[: x.shape[1]], s[x.shape[1]:]
 
 
+def bn_stats_packed(x):
+    """-> f64 (2c+1): [sum(c), sumsq(c), unset count slot] - the buffer SyncBatchNorm all-reduces"""
+    _req(x, torch.float32, "x", 2)
+    s = torch.empty(2 * x.shape[1] + 1, dtype=torch.float64, device=x.device)
+    check(lib().xm3d_bn_stats(_ptr(x), x.shape[0], x.shape[1], _ptr(s), _stream()), "xm3d_bn_stats")
+    return s
+
+
+def bn_finalize(packed, c, total, weight, bias, eps, momentum=None, running_mean=None, running_var=None, num_batches=None):
+    """-> mean, invstd, scale, shift (c,) f32 and total (1,) f32; momentum given: running buffers updated in place."""
+    dev = packed.device
+    out = torch.empty(4 * c + 4, dtype=torch.float32, device=dev)  # one allocation; slices stay 16-byte aligned for c % 4 == 0
+    mean, invstd, scale, shift, tot = out[:c], out[c:2 * c], out[2 * c:3 * c], out[3 * c:4 * c], out[4 * c:4 * c + 1]
+    check(lib().xm3d_bn_finalize(_ptr(packed), c, float(total), _ptr(weight), _ptr(bias), float(eps),
+                                 -1.0 if momentum is None else float(momentum), _ptr(running_mean), _ptr(running_var), _ptr(num_batches),
+                                 _ptr(mean), _ptr(invstd), _ptr(scale), _ptr(shift), _ptr(tot), _stream()), "xm3d_bn_finalize")
+    return mean, invstd, scale, shift, tot
+
+
+def bn_bwd_reduce(gy, x, mean, invstd):
+    _req(gy, torch.float32, "gy", 2)
+    _req(x, torch.float32, "x", 2)
+    sums = torch.empty(2 * x.shape[1], dtype=torch.float64, device=x.device)
+    check(lib().xm3d_bn_bwd_reduce(_ptr(gy), _ptr(x), x.shape[0], x.shape[1], _ptr(mean), _ptr(invstd), _ptr(sums), _stream()),
+          "xm3d_bn_bwd_reduce")
+    return sums
+
+
+def bn_bwd_apply(gy, x, mean, invstd, weight, sums, total, need_wb=True):
+    c = x.shape[1]
+    gx = torch.empty_like(x)
+    gwb = torch.empty(2 * c, dtype=torch.float32, device=x.device) if need_wb else None
+    check(lib().xm3d_bn_bwd_apply(_ptr(gy), _ptr(x), x.shape[0], c, _ptr(mean), _ptr(invstd), _ptr(weight), _ptr(sums), _ptr(total),
+                                  _ptr(gx), _ptr(gwb[:c]) if need_wb else None, _ptr(gwb[c:]) if need_wb else None, _stream()),
+          "xm3d_bn_bwd_apply")
+    return gx, (gwb[:c] if need_wb else None), (gwb[c:] if need_wb else None)
+
+
 def affine_act(x, scale=None, shift=None, residual=None, relu=False, out=None):
     _req(x, torch.float32, "x", 2)
     if out is None:
