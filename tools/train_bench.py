@@ -11,7 +11,7 @@ from xmask3d_amd.xmask3d import XMASK3d
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 2
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 5
-dtype = torch.bfloat16 if (len(sys.argv) > 3 and sys.argv[3] == "bf16") else torch.float32
+dtype = torch.bfloat16 if "bf16" in sys.argv[3:] else torch.float32
 rank, world, local = int(os.environ.get("RANK", 0)), int(os.environ.get("WORLD_SIZE", 1)), int(os.environ.get("LOCAL_RANK", 0))
 torch.cuda.set_device(local)
 dev = torch.device("cuda", local)
@@ -20,6 +20,10 @@ if world > 1:
 cfg = load_cfg_from_cfg_file(os.path.join(ROOT, "configs", "xmask3d_scannet_B15N4.yaml"))
 torch.manual_seed(cfg.manual_seed)
 model = XMASK3d(cfg).to(dev).set_dense_dtype(dtype).train()
+if "cl" in sys.argv[3:]:
+    model.set_channels_last(True)
+if "graph" in sys.argv[3:]:
+    model.backbone.feature_extractor.ldm_extractor.enable_train_graph()
 if world > 1:
     ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)      # per-GPU batch < 4 (run/train.py:185-187)
     model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)

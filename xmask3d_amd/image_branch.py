@@ -103,6 +103,7 @@ class LdmExtractor(nn.Module):
         n = len(self.encoder_block_indices) + len(self.unet_block_indices) + len(self.decoder_block_indices)
         return [[i] for i in range(n)]
 
+    @torch.no_grad()  # frozen weights, image-only input: nothing upstream needs a gradient (fused inference kernels apply)
     def encode(self, img):
         """VAE encoder stage: img (B,3,H,W) in [0,1] -> (latent (B,4,H/8,W/8), tapped encoder features).  Independent of the
         3D conditioning, so it can run concurrently with the sparse 3D branch."""
@@ -112,6 +113,7 @@ class LdmExtractor(nn.Module):
         moments = ldm.first_stage_model.quant_conv(moments)
         return SCALE_FACTOR * moments[:, :4], enc_feats  # posterior mean
 
+    @torch.no_grad()  # depends on the image only (through the latent): no gradient path to any trainable parameter
     def decode_taps(self, latent):
         z = self.ldm.first_stage_model.post_quant_conv(latent / SCALE_FACTOR)
         return self.ldm.decoder(z, taps=self.decoder_block_indices, stop_after_taps=self.prune_dead_compute)[1]
@@ -125,6 +127,28 @@ class LdmExtractor(nn.Module):
         return self.ldm.unet(noisy, t, cond_inputs, cond_emb=cond_emb[:, 0], taps=self.unet_block_indices,
                              stop_after_taps=self.prune_dead_compute)[1]
 
+    def enable_train_graph(self, on=True):
+        """Training: replay the frozen UNet's forward AND backward as HIP graphs (torch.cuda.make_graphed_callables), one
+        pair per input shape.  The UNet is the only frozen net a gradient passes through (to the 3D conditioning); eagerly
+        its ~1500 forward and ~3000 backward launches are host-bound at one view per GPU."""
+        self._train_graphs = {} if on else None
+        return self
+
+    def _unet_taps_graphed(self, latent, cond_inputs, cond_emb):
+        key = (tuple(latent.shape), latent.dtype, tuple(cond_inputs.shape), latent.is_contiguous(memory_format=torch.channels_last))
+        fn = self._train_graphs.get(key)
+        if fn is None:
+            ext = self
+
+            class _UNetTaps(nn.Module):  # no registered parameters: the frozen weights are constants of the graph
+                def forward(self, lat, ctx, emb):
+                    return tuple(ext.unet_taps(lat, ctx, emb))
+
+            sample = (latent.detach().clone(), cond_inputs.detach().clone().requires_grad_(True),
+                      cond_emb.detach().clone().requires_grad_(True))
+            fn = self._train_graphs[key] = torch.cuda.make_graphed_callables(_UNetTaps().eval(), sample)
+        return list(fn(latent, cond_inputs, cond_emb))
+
     def from_latent(self, latent, enc_feats, cond_inputs, cond_emb, fork_stream=None):
         """UNet taps and VAE-decoder taps from the latent.  The two are independent: with `fork_stream` (graph capture)
         the decoder is enqueued on that stream and joined afterwards, so the captured graph runs them side by side."""
@@ -136,7 +160,11 @@ class LdmExtractor(nn.Module):
             unet_feats = self.unet_taps(latent, cond_inputs, cond_emb)
             cur.wait_stream(fork_stream)
         else:
-            unet_feats = self.unet_taps(latent, cond_inputs, cond_emb)
+            if getattr(self, "_train_graphs", None) is not None and torch.is_grad_enabled() and latent.is_cuda \
+                    and cond_inputs.requires_grad and cond_emb.requires_grad:
+                unet_feats = self._unet_taps_graphed(latent, cond_inputs, cond_emb)
+            else:
+                unet_feats = self.unet_taps(latent, cond_inputs, cond_emb)
             dec_feats = self.decode_taps(latent)
         return [*enc_feats, *unet_feats, *dec_feats]
 
