@@ -63,6 +63,9 @@ def train(cfg, epochs=1, iters_per_epoch=4, views_per_gpu=2, save_path=None, res
     torch.manual_seed(cfg.manual_seed)
     np.random.seed(cfg.manual_seed + rank)
     model = XMASK3d(cfg).to(dev)
+    if dev.type == "cuda" and bool(getattr(cfg, "train_unet_graph", True)):
+        # the frozen UNet's forward + backward replay as HIP graphs (it has no trainable parameter: DDP never sees it)
+        model.backbone.feature_extractor.ldm_extractor.enable_train_graph()
     if world > 1:
         if views_per_gpu < 4:
             ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)

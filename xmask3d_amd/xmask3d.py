@@ -85,7 +85,10 @@ class XMASK3d(nn.Module):
             feature_extractor=LdmImplicitCaptionerExtractor(
                 encoder_block_indices=(5, 7), unet_block_indices=(2, 5, 8, 11), decoder_block_indices=(2, 5), steps=(0,),
                 learnable_time_embed=True, num_timesteps=1, dim_latent=768, clip=None, prune_dead_compute=prune_dead_compute),
-            out_features=["s2", "s3", "s4", "s5"], use_checkpoint=True, slide_training=False)
+            out_features=["s2", "s3", "s4", "s5"],
+            # the reference re-computes the projections in backward (use_checkpoint=True, odise backbone) to fit 24-80 GB cards;
+            # with 288 GB of HBM the activations simply stay resident (same values, one forward less per iteration)
+            use_checkpoint=bool(getattr(cfg, "activation_checkpointing", False)), slide_training=False)
         self.sem_seg_head = MaskFormerHead(
             ignore_value=255, num_classes=num_classes,
             pixel_decoder=MSDeformAttnPixelDecoder(
