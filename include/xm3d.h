@@ -179,6 +179,14 @@ int xm3d_bias_residual_nhwc(const void* a, const void* b, const void* bias, int3
  * x[:, :D] * gelu(x[:, D:]) (exact erf GELU, f32 arithmetic). */
 int xm3d_geglu(const void* x, int32_t dtype, int64_t rows, int32_t D, void* out, void* stream);
 
+/* ---- masked cross-attention bias (replaces the mask handling of Mask2Former's decoder, XMask3D copy
+ * third_party/.../odise.py:395,445-491: bilinear shrink -> sigmoid -> < 0.5 -> repeat over heads -> all/and-not -> -inf fill).
+ * logits (maps, H, W) mask logits (maps = B*Q), in_dtype/out_dtype 0 = f32, 1 = bf16; (H,W) -> (h,w) must be a shrink by
+ * an even integer factor, h*w <= 8192.  out (maps, h*w): 0 where the query may attend, -inf where its predicted mask
+ * is < 0.5; a query with no open position gets all zeros.  Bit-identical to the op chain it replaces. */
+int xm3d_attn_mask_bias(const void* logits, int32_t in_dtype, int64_t maps, int32_t H, int32_t W, int32_t h, int32_t w, void* out,
+                        int32_t out_dtype, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Multi-scale deformable attention (replaces the pybind module
  * MultiScaleDeformableAttention: third_party/Mask2Former/mask2former/modeling/

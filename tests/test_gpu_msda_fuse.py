@@ -236,3 +236,43 @@ def test_pointwise_fusions_match_torch(dev, dtype):
         out = ops.group_norm(a, 32, w, bb, 1e-5, 1, shift)
         assert out.is_contiguous(memory_format=torch.channels_last)
         assert (out.float() - ref).abs().max().item() <= max(tol, 2e-5) * max(ref.abs().max().item(), 1.0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_attn_mask_bias_equals_the_op_chain(dev, dtype):
+    """xm3d_attn_mask_bias == bilinear shrink -> sigmoid -> < 0.5 -> all/and-not -> -inf fill (odise.py:395,445-491), bit for bit"""
+    import torch.nn.functional as F
+    from xmask3d_amd import ops
+
+    torch.manual_seed(4)
+    logits = (torch.randn(5, 50, 128, 128, device=dev) * 3).to(dtype)
+    logits[1, 7] = -5.0          # a query whose mask is empty everywhere: attends to everything
+    logits[2, 3] = 0.0           # sigmoid == 0.5 exactly: not masked
+    for t in (16, 32, 64):
+        with torch.no_grad():
+            m = F.interpolate(logits, size=(t, t), mode="bilinear", align_corners=False).sigmoid().flatten(2) < 0.5
+            m = m & ~m.all(dim=-1, keepdim=True)
+            want = torch.zeros(m.shape, dtype=dtype, device=dev).masked_fill(m, float("-inf"))
+            got = ops.attn_mask_bias(logits, (t, t), dtype)
+        assert got.shape == (5, 50, t * t) and torch.equal(got, want)
+        assert float(got[1, 7].abs().max()) == 0.0 and bool(torch.isinf(got).any())
+
+
+@pytest.mark.gpu
+def test_cross_attention_bias_path_equals_multihead_attention(dev):
+    """CrossAttentionLayer(memory_bias=...) (manual projections + SDPA, bias broadcast over heads) == nn.MultiheadAttention with
+    the replicated boolean mask"""
+    from xmask3d_amd.mask_head import CrossAttentionLayer
+
+    torch.manual_seed(5)
+    layer = CrossAttentionLayer(256, 8).to(dev).eval()
+    tgt, qpos = torch.randn(50, 3, 256, device=dev), torch.randn(50, 3, 256, device=dev)
+    mem, pos = torch.randn(1024, 3, 256, device=dev), torch.randn(1024, 3, 256, device=dev)
+    mask = torch.rand(3, 50, 1024, device=dev) < 0.6
+    mask[0, 0] = False
+    bias = torch.zeros(3, 50, 1024, device=dev).masked_fill(mask, float("-inf"))
+    with torch.no_grad():
+        ref = layer(tgt, mem, memory_mask=mask[:, None].repeat(1, 8, 1, 1).flatten(0, 1), pos=pos, query_pos=qpos)
+        out = layer(tgt, mem, memory_bias=bias, pos=pos, query_pos=qpos)
+    assert (out - ref).abs().max().item() < 2e-5 * ref.abs().max().item()

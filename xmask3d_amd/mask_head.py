@@ -239,10 +239,28 @@ class CrossAttentionLayer(nn.Module):
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
 
-    def forward(self, tgt, memory, memory_mask=None, pos=None, query_pos=None, key=None):
-        """key: memory + pos when the caller has it already (the same level feeds three layers)"""
-        tgt2 = self.multihead_attn(query=tgt + query_pos, key=memory + pos if key is None else key, value=memory,
-                                   attn_mask=memory_mask, need_weights=False)[0]
+    def forward(self, tgt, memory, memory_mask=None, pos=None, query_pos=None, key=None, memory_bias=None):
+        """key: memory + pos when the caller has it already (the same level feeds three layers).
+        memory_bias (B, Q, K) additive float mask (xm3d_attn_mask_bias) instead of the boolean memory_mask (B*heads, Q, K):
+        inference path, the same projections / scaled_dot_product_attention / out-projection nn.MultiheadAttention runs,
+        with the bias broadcast over the heads instead of replicated and converted per call."""
+        key = memory + pos if key is None else key
+        if memory_bias is None:
+            tgt2 = self.multihead_attn(query=tgt + query_pos, key=key, value=memory, attn_mask=memory_mask, need_weights=False)[0]
+            return self.norm(tgt + tgt2)
+        mha = self.multihead_attn
+        E, H = mha.embed_dim, mha.num_heads
+        w, b = mha.in_proj_weight, mha.in_proj_bias
+        q = F.linear(tgt + query_pos, w[:E], b[:E])
+        k = F.linear(key, w[E:2 * E], b[E:2 * E])
+        v = F.linear(memory, w[2 * E:], b[2 * E:])
+        Lq, B = q.shape[:2]
+        Lk = k.shape[0]
+        q = q.view(Lq, B, H, E // H).permute(1, 2, 0, 3)
+        k = k.view(Lk, B, H, E // H).permute(1, 2, 0, 3)
+        v = v.view(Lk, B, H, E // H).permute(1, 2, 0, 3)
+        o = F.scaled_dot_product_attention(q, k, v, attn_mask=memory_bias.view(B, 1, Lq, Lk).to(q.dtype))
+        tgt2 = F.linear(o.permute(2, 0, 1, 3).reshape(Lq, B, E), mha.out_proj.weight, mha.out_proj.bias)
         return self.norm(tgt + tgt2)
 
 
@@ -383,11 +401,15 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
         cls_l.append(c), mask_l.append(m), extra_l.append(e)
         for i in range(self.num_layers):
             lvl = i % self.num_feature_levels
-            # a query whose mask is empty everywhere attends to everything (odise.py:395)
-            full = attn_mask.all(dim=-1, keepdim=True)
-            attn_mask = attn_mask & ~full
-            output = self.transformer_cross_attention_layers[i](output, src[lvl], memory_mask=attn_mask, pos=pos[lvl],
-                                                                query_pos=query_embed, key=keys[lvl])
+            if attn_mask.dtype == torch.bool:
+                # a query whose mask is empty everywhere attends to everything (odise.py:395)
+                full = attn_mask.all(dim=-1, keepdim=True)
+                attn_mask = attn_mask & ~full
+                output = self.transformer_cross_attention_layers[i](output, src[lvl], memory_mask=attn_mask, pos=pos[lvl],
+                                                                    query_pos=query_embed, key=keys[lvl])
+            else:  # additive bias from xm3d_attn_mask_bias (that rule is applied inside the kernel)
+                output = self.transformer_cross_attention_layers[i](output, src[lvl], memory_bias=attn_mask, pos=pos[lvl],
+                                                                    query_pos=query_embed, key=keys[lvl])
             output = self.transformer_self_attention_layers[i](output, query_pos=query_embed)
             output = self.transformer_ffn_layers[i](output)
             c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[(i + 1) % self.num_feature_levels],
@@ -404,12 +426,20 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
 
     def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, with_embed=True):
         decoder_output = self.decoder_norm(output).transpose(0, 1)
-        outputs_class = self.class_embed(decoder_output)
+        # (the class logits of a layer whose pooled embedding is pruned feed nothing either: same switch)
+        outputs_class = self.class_embed(decoder_output) if with_embed else None
         mask_embed = self.mask_embed(decoder_output)
         outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
         extra = {}
         if self.post_mask_embed is not None and with_embed:
             extra.update(self.post_mask_embed(decoder_output, mask_embed, mask_features, outputs_class, outputs_mask))
+        if outputs_mask.is_cuda and not torch.is_grad_enabled() and outputs_mask.dtype in (torch.float32, torch.bfloat16):
+            from . import ops
+
+            if ops.attn_mask_bias_supported(outputs_mask.shape, attn_mask_target_size):
+                qdt = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else torch.float32
+                if qdt in (torch.float32, torch.bfloat16):  # one launch: shrink, threshold, empty-mask rule, additive bias
+                    return outputs_class, outputs_mask, ops.attn_mask_bias(outputs_mask, attn_mask_target_size, qdt), extra
         attn_mask = bilinear_down(outputs_mask, attn_mask_target_size)
         attn_mask = (attn_mask.sigmoid().flatten(2).unsqueeze(1).repeat(1, self.num_heads, 1, 1).flatten(0, 1) < 0.5).bool()
         return outputs_class, outputs_mask, attn_mask.detach(), extra

@@ -383,6 +383,25 @@ def bias_residual(a, b, bias):
     return out
 
 
+def attn_mask_bias(logits, size, out_dtype):
+    """mask logits (B,Q,H,W) f32/bf16 -> additive attention bias (B,Q,h*w) of dtype out_dtype (0 / -inf), see xm3d.h"""
+    if not logits.is_cuda or logits.dtype not in (torch.float32, torch.bfloat16) or out_dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("attn_mask_bias: f32/bf16 device tensors required")
+    logits = logits.contiguous()
+    B, Q, H, W = logits.shape
+    h, w = int(size[0]), int(size[1])
+    out = torch.empty((B, Q, h * w), dtype=out_dtype, device=logits.device)
+    check(lib().xm3d_attn_mask_bias(_ptr(logits), 0 if logits.dtype == torch.float32 else 1, B * Q, H, W, h, w, _ptr(out),
+                                    0 if out_dtype == torch.float32 else 1, _stream()), "xm3d_attn_mask_bias")
+    return out
+
+
+def attn_mask_bias_supported(shape, size):
+    H, W = shape[-2:]
+    h, w = int(size[0]), int(size[1])
+    return H % h == 0 and W % w == 0 and (H // h) % 2 == 0 and (W // w) % 2 == 0 and h * w <= 8192
+
+
 def geglu(x):
     """x (..., 2D) contiguous f32/bf16 device tensor -> (..., D) = x[..., :D] * gelu(x[..., D:])"""
     if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or not x.is_contiguous() or x.shape[-1] % 2:
