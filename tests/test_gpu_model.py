@@ -185,6 +185,26 @@ def test_cross_scene_prefetch_does_not_change_results(dev, models):
         assert (x == y).float().mean().item() > 0.995 and (x == z).float().mean().item() > 0.995
 
 
+def test_two_scenes_per_forward_equal_single_scene_inference(dev, models):
+    """pipeline.infer_scenes: 2 scenes x 5 views in one forward (batch 10) -> the same votes as one scene per forward"""
+    from xmask3d_amd import pipeline, synthetic
+
+    cfg, _, gpu = models
+    g = copy.deepcopy(gpu).enable_dense_graph()
+    sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
+    T = [np.diag([50.0, 50.0, 50.0, 1.0])] * 5
+    vox = pipeline.default_voxelizer(device=dev)
+    one = pipeline.infer_scene(g, sd, cfg, vox, T)
+    M = [T, T]
+    two = pipeline.infer_scenes(g, [sd, sd], cfg, vox, M, next_scenes=[sd, sd], next_matrices=M)
+    assert g._next_front is not None
+    again = pipeline.infer_scenes(g, [sd, sd], cfg, vox, M)   # consumes the prefetched front of the group
+    assert g._next_front is None and len(two) == 2 and len(again) == 2
+    for res in two + again:
+        for x, y in zip(one, res):
+            assert x.shape == y.shape and (x == y).float().mean().item() > 0.995
+
+
 @pytest.mark.parametrize("name,n_train,n_test", [("xmask3d_scannet_B12N7", 12, 19), ("xmask3d_scannet_B170N30", 170, 200)])
 def test_other_benchmark_configs_run(dev, name, n_train, n_test):
     """BASELINE.json configs 4 and 5: novel-class stress (12 base / 7 novel) and the 200-class head (170/30, Q stays 50)."""

@@ -20,7 +20,7 @@ if "heads16" in sys.argv[2:]:
     model.cast_head_weights()
 sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
 vox = pipeline.default_voxelizer(device=dev)
-batch = pipeline.build_scene_batch(sd, list(range(B)), vox, [np.diag([50.0, 50.0, 50.0, 1.0])] * B)
+batch = pipeline.build_scene_batch(sd, [i % 5 for i in range(B)], vox, [np.diag([50.0, 50.0, 50.0, 1.0])] * B)
 
 
 def graph_time(fn, reps=10):

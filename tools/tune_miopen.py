@@ -22,8 +22,8 @@ sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
 vox = pipeline.default_voxelizer(device=dev)
 T = np.diag([50.0, 50.0, 50.0, 1.0])
 with torch.no_grad():
-    for B in (5, 1):
-        batch = pipeline.build_scene_batch(sd, list(range(B)), vox, [T] * B)
+    for B in ([int(a) for a in sys.argv[1:]] or [5, 1]):
+        batch = pipeline.build_scene_batch(sd, [i % 5 for i in range(B)], vox, [T] * B)
         t = time.time()
         model(batch)
         torch.cuda.synchronize()

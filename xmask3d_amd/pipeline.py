@@ -72,30 +72,46 @@ def build_view_batch(sd: SceneOnDevice, view: int, voxelizer: Voxelizer, matrix=
 def build_scene_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, matrices=None):
     """All (or some) views of a scene as ONE batch: views are independent until the vote, so they are collated like a
     DataLoader batch (batch index in column 0 of coords / ori_coords, inds_reconstruct offset per view)."""
-    coords, feats, inv, ori, xs, ys, imgs, caps = [], [], [], [], [], [], [], []
-    base = 0
+    return build_group_batch([(sd, list(views))], voxelizer, None if matrices is None else [matrices])
+
+
+def build_group_batch(groups, voxelizer: Voxelizer, matrices=None):
+    """Views of one or several scenes as ONE batch.  groups: [(SceneOnDevice, [view, ...]), ...]; matrices: per group, a list
+    of 4x4 voxelisation transforms per view (None: drawn from np.random in scene-by-scene, view-by-view order, as a
+    sequential run would).  Batch entry b = position in the flattened (scene, view) list."""
+    coords, feats, inv, ori, caps = [], [], [], [], []
+    xs, ys, imgs, vids = [], [], [], []
+    base, b = 0, 0
     offsets = [0]
-    for b, v in enumerate(views):
-        vw = sd.views[v]
-        pts = sd.points[vw["idx"]].contiguous()
-        offsets.append(offsets[-1] + pts.shape[0])
-        grid, inds, inverse = voxelizer.voxelize_device(pts, None if matrices is None else matrices[b])
-        coords.append(torch.cat([torch.full((grid.shape[0], 1), b, dtype=torch.int32, device=sd.device), grid], 1))
-        feats.append((sd.colors[vw["idx"]][inds] / 127.5 - 1.0).float())
-        inv.append(inverse + base)
-        base += grid.shape[0]
-        ori.append(torch.cat([torch.full((pts.shape[0], 1), float(b), device=sd.device), pts.float()], 1))
-        xs.append(vw["x"]); ys.append(vw["y"]); imgs.append(vw["img"]); caps.append(vw["caption"])
+    dev = groups[0][0].device
+    for gi, (sd, views) in enumerate(groups):
+        whole = list(views) == list(range(len(sd.views)))
+        b0 = b
+        for vi, v in enumerate(views):
+            vw = sd.views[v]
+            pts = sd.points[vw["idx"]].contiguous()
+            offsets.append(offsets[-1] + pts.shape[0])
+            grid, inds, inverse = voxelizer.voxelize_device(pts, None if matrices is None or matrices[gi] is None else matrices[gi][vi])
+            coords.append(torch.cat([torch.full((grid.shape[0], 1), b, dtype=torch.int32, device=dev), grid], 1))
+            feats.append((sd.colors[vw["idx"]][inds] / 127.5 - 1.0).float())
+            inv.append(inverse + base)
+            base += grid.shape[0]
+            ori.append(torch.cat([torch.full((pts.shape[0], 1), float(b), device=dev), pts.float()], 1))
+            caps.append(vw["caption"])
+            if not whole:
+                xs.append(vw["x"]); ys.append(vw["y"]); imgs.append(vw["img"])
+                vids.append(torch.full((pts.shape[0],), b, dtype=torch.long, device=dev))
+            b += 1
+        if whole:  # per-scene tables built once at upload
+            xs.append(sd.x_all); ys.append(sd.y_all); imgs.append(sd.img_all)
+            vids.append(sd.view_all if b0 == 0 else sd.view_all + b0)
     coords = torch.cat(coords).contiguous()
-    if list(views) == list(range(len(sd.views))):
-        img, x_all, y_all, view_all = sd.img_all, sd.x_all, sd.y_all, sd.view_all
-    else:
-        img, x_all, y_all = torch.cat(imgs), torch.cat(xs), torch.cat(ys)
-        view_all = torch.cat([torch.full((offsets[b + 1] - offsets[b],), b, dtype=torch.long, device=sd.device) for b in range(len(views))])
-    return {"sinput": ME.SparseTensor(torch.cat(feats).contiguous(), coords), "img": img, "x_label": x_all,
-            "y_label": y_all, "inds_reconstruct": torch.cat(inv), "ori_coords": torch.cat(ori), "captions": tuple(caps),
+    one = len(xs) == 1
+    return {"sinput": ME.SparseTensor(torch.cat(feats).contiguous(), coords), "img": imgs[0] if one else torch.cat(imgs),
+            "x_label": xs[0] if one else torch.cat(xs), "y_label": ys[0] if one else torch.cat(ys),
+            "inds_reconstruct": torch.cat(inv), "ori_coords": torch.cat(ori), "captions": tuple(caps),
             "coords": coords, "label_2d": None, "labels_3d": None, "use_pure_3d": False, "point_offsets": offsets,
-            "point_view": view_all}
+            "point_view": vids[0] if one else torch.cat(vids)}
 
 
 def build_train_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, seed=0, n_classes=15, ignore=(19, 20)):
@@ -320,3 +336,57 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
             nbatch["compact_outputs"] = False
         model._next_front = dict(scene=next_scene, matrices=next_matrices, batch=nbatch, front=model.eval_front(nbatch, stream=fs))
     return result
+
+
+@torch.no_grad()
+def infer_scenes(model, sds, cfg, voxelizer=None, matrices=None, with_ablations=True, next_scenes=None, next_matrices=None):
+    """infer_scene for a GROUP of scenes whose views all go through ONE forward (e.g. 2 scenes x 5 views = batch 10): the
+    views are independent until the vote, and the latency-bound stages (decoders, post-processing) cost almost the same for
+    10 views as for 5 - 36.5 instead of 46.5 ms of dense-branch time per scene (tools/prof_stages.py).  Per-view results
+    do not depend on the grouping.  matrices: per scene, a list of 4x4 transforms per view (or None).  next_scenes
+    (+ next_matrices): the group inferred next; its front is issued on side streams like infer_scene(next_scene=...).
+    -> list (per scene) of [fused, 2D-only, 3D-only] per-point predictions."""
+    sds = list(sds)
+    dev = sds[0].device
+    if dev.type != "cuda" or getattr(model, "_dense_graphs", None) is None or model.training:
+        return [infer_scene(model, sd, cfg, voxelizer, None if matrices is None else matrices[j], with_ablations)
+                for j, sd in enumerate(sds)]
+    voxelizer = voxelizer or default_voxelizer(cfg.voxel_size, dev)
+    ncls = len(cfg.category_split["base_category"]) + len(cfg.category_split["novel_category"])
+
+    def same(a, b):
+        return a is not None and b is not None and len(a) == len(b) and all(x is y for x, y in zip(a, b))
+
+    pending, model._next_front = getattr(model, "_next_front", None), None
+    if pending is not None and same(pending.get("scenes"), sds) and pending["matrices"] is matrices:
+        batch, front = pending["batch"], pending["front"]
+    else:
+        batch = build_group_batch([(sd, list(range(len(sd.views)))) for sd in sds], voxelizer, matrices)
+        batch["compact_outputs"] = False
+        front = model.eval_front(batch)
+    outputs = model.eval_fuse(batch, front, model.eval_dense(batch, front))
+    model.mark("F1")
+    preds = postprocess_scene(cfg, outputs, batch, with_ablations)
+    off = batch["point_offsets"]
+    results, v0 = [], 0
+    for sd in sds:
+        lo, hi = off[v0], off[v0 + len(sd.views)]
+        v0 += len(sd.views)
+        votes = []
+        for p in preds:
+            if p is not None:
+                vt = torch.zeros((sd.n, ncls), dtype=torch.int32, device=dev)
+                pj = p[lo:hi]
+                votes.append(vt.index_put_((sd.idx_all, pj), torch.ones_like(pj, dtype=torch.int32), accumulate=True))
+        seen = torch.zeros(sd.n, dtype=torch.bool, device=dev).index_fill_(0, sd.idx_all, True)
+        fill = nearest_valid_fill(sd.points, seen)
+        results.append([vt.argmax(1)[fill] for vt in votes] + [None] * (3 - len(votes) if not with_ablations else 0))
+    model.mark("P1")
+    if next_scenes is not None:
+        nxt = list(next_scenes)
+        fs = model.front_stream()
+        with torch.cuda.stream(fs):
+            nbatch = build_group_batch([(sd, list(range(len(sd.views)))) for sd in nxt], voxelizer, next_matrices)
+            nbatch["compact_outputs"] = False
+        model._next_front = dict(scenes=nxt, scene=None, matrices=next_matrices, batch=nbatch, front=model.eval_front(nbatch, stream=fs))
+    return results
