@@ -94,13 +94,13 @@ def spconv_roofline(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="dtype of the frozen dense nets (SD, CLIP)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views-per-batch", type=int, default=0, help="views per forward (0 = all views of the scene; 1 = reference loop)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find through the shipped find-db)")
-    ap.add_argument("--scenes-per-forward", type=int, default=2,
+    ap.add_argument("--scenes-per-forward", type=int, default=4,
                     help="scenes whose views share one forward (views are independent until the vote); 1 = one scene per forward")
     ap.add_argument("--nchw", action="store_true", help="keep NCHW activations in the frozen conv nets (default: channels-last)")
     ap.add_argument("--no-graph", action="store_true", help="launch the dense branch eagerly instead of replaying a HIP graph")
