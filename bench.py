@@ -173,6 +173,10 @@ def main():
 
     G = 1 if (args.no_graph or args.views_per_batch) else max(1, args.scenes_per_forward)
 
+    def group_sizes(n_scenes):  # ceil(n/G) groups, as even as possible (5 scenes at G=4 -> 3+2, not 4+1)
+        ng = -(-n_scenes // G)
+        return [n_scenes // ng + (1 if i < n_scenes % ng else 0) for i in range(ng)]
+
     def run(n_scenes):
         """n_scenes steps (one step = one scene).  Scenes go through the model in groups of G (all views of the group in
         one forward); consecutive groups are software-pipelined (the next group's front is issued on side streams)."""
@@ -180,7 +184,7 @@ def main():
             for k in range(n_scenes):
                 out = pipeline.infer_scene(model, sd, cfg, voxelizer, views_per_batch=args.views_per_batch or None)
             return out
-        sizes = [G] * (n_scenes // G) + ([n_scenes % G] if n_scenes % G else [])
+        sizes = group_sizes(n_scenes)
         for gi, g in enumerate(sizes):
             nxt = [sd] * sizes[gi + 1] if gi + 1 < len(sizes) else None
             out = pipeline.infer_scenes(model, [sd] * g, cfg, voxelizer, next_scenes=nxt)[-1]
@@ -189,7 +193,7 @@ def main():
     if not args.no_graph and not args.views_per_batch:
         # setup, not a step: capture the HIP graphs of every batch shape the timed region will meet
         with torch.no_grad():
-            for g in sorted({G, 1} | ({args.steps % G, args.warmup % G} - {0})):
+            for g in sorted(set(group_sizes(args.steps)) | set(group_sizes(1))):
                 model._graphs_for(torch.cat([sd.img_all] * g), torch.zeros(g * len(sd.views), 768, device=dev))
         torch.cuda.synchronize()
         log(f"HIP graphs captured for {G} scene(s) per forward")
