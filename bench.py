@@ -94,7 +94,7 @@ def spconv_roofline(dev):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=16)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"], help="dtype of the frozen dense nets (SD, CLIP)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -203,6 +203,13 @@ def main():
         torch.cuda.synchronize()
         log(f"warmup step {i} done")
     torch.cuda.synchronize()
+    # the model, its HIP graphs and the scene tables are millions of long-lived python objects: move them to the permanent
+    # generation so that a cyclic-GC pass inside the timed loop stays cheap (an unfrozen gen-2 pass stalls the host ~50 ms,
+    # which delays the next forward: tools/timeline_events.py with and without "nogc")
+    import gc
+
+    gc.collect()
+    gc.freeze()
     if world > 1:
         dist.barrier()
     from xmask3d_amd import ops as _ops

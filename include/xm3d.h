@@ -217,6 +217,11 @@ int xm3d_msda_backward(const float* value, const int64_t* spatial_shapes, const 
 int xm3d_mask_point_fuse(const uint8_t* masks, int32_t Q, int32_t Hm, int32_t Wm, const int64_t* x,
                          const int64_t* y, int64_t n, const float* embed, int32_t C, float* feat2d,
                          int32_t* count, void* stream);
+/* Pixel ownership among the mask queries (models/xmask3d.py:372-392): logits (B,Q,hw) f32 mask logits at mask_shape,
+ * score (B,Q) f32, keep (B,Q) u8.  owner (B,hw) i32 = the first arg-max over q of (keep ? score : -1) * sigmoid(logit) if
+ * that query is kept and its sigmoid >= 0.5 there, else -1.  The reference's per-query binary masks are owner == q. */
+int xm3d_mask_owner(const float* logits, const float* score, const uint8_t* keep, int32_t B, int32_t Q, int64_t hw, int32_t* owner,
+                    void* stream);
 
 /* ---------------------------------------------------------------------------
  * Exact 1-nearest-neighbour index (replaces sklearn.neighbors.KDTree(...).query(k=1) in run/infer.py:523-553,

@@ -276,3 +276,27 @@ def test_cross_attention_bias_path_equals_multihead_attention(dev):
         ref = layer(tgt, mem, memory_mask=mask[:, None].repeat(1, 8, 1, 1).flatten(0, 1), pos=pos, query_pos=qpos)
         out = layer(tgt, mem, memory_bias=bias, pos=pos, query_pos=qpos)
     assert (out - ref).abs().max().item() < 2e-5 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_mask_owner_equals_the_op_chain(dev):
+    """xm3d_mask_owner == sigmoid / (kept ? score : -1) product / argmax / (>= 0.5) & keep chain of models/xmask3d.py:372-392"""
+    from xmask3d_amd import ops
+
+    torch.manual_seed(6)
+    B, Q, H, W = 3, 50, 60, 80
+    logits = (torch.randn(B, Q, H, W, device=dev) * 2)
+    logits[0, :, :5] = -9.0                     # pixels no query claims
+    logits[1, 3] = logits[1, 7]                 # exact ties: the lower query id wins
+    scores = torch.rand(B, Q, device=dev)
+    scores[1, 3] = scores[1, 7]
+    keep = torch.rand(B, Q, device=dev) < 0.7
+    keep[2] = False                             # nothing kept: no owner anywhere
+    mask_pred = logits.sigmoid()
+    prob = torch.where(keep, scores, torch.full_like(scores, -1.0)).view(B, Q, 1, 1) * mask_pred
+    ids = prob.argmax(1)
+    final = (ids[:, None] == torch.arange(Q, device=dev).view(1, -1, 1, 1)) & (mask_pred >= 0.5) & keep.view(B, Q, 1, 1)
+    want = torch.where(final.any(1), ids, torch.full_like(ids, -1)).int()
+    got = ops.mask_owner(logits, scores, keep)
+    assert torch.equal(got, want)
+    assert int((got[2] >= 0).sum()) == 0 and int((got[0, :5] >= 0).sum()) == 0

@@ -9,7 +9,7 @@ from xmask3d_amd.config import load_cfg_from_cfg_file
 from xmask3d_amd.xmask3d import XMASK3d
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 6
-G = int(sys.argv[2]) if len(sys.argv) > 2 else 1   # scenes per forward
+G = int(sys.argv[2]) if len(sys.argv) > 2 and sys.argv[2].isdigit() else 1   # scenes per forward
 dev = torch.device("cuda:0")
 cfg = load_cfg_from_cfg_file(os.path.join(ROOT, "configs", "xmask3d_scannet_B15N4.yaml"))
 torch.manual_seed(0)
@@ -26,6 +26,9 @@ with torch.no_grad():
     for _ in range(3):
         go()
     torch.cuda.synchronize()
+    if "nogc" in sys.argv:
+        import gc
+        gc.collect(); gc.freeze(); gc.disable()
     model._trace = []
     base = torch.cuda.Event(enable_timing=True); base.record()
     host = []

@@ -54,9 +54,47 @@ __global__ void k_mask_point_fuse(const uint8_t* __restrict__ masks, int Q, int 
     if (lane == 0) count[p] = cnt;
 }
 
+// Pixel ownership among the mask queries (models/xmask3d.py:372-392 / criterion.py:245-328, the panoptic-style merge):
+//   prob[q] = (keep[q] ? score[q] : -1) * sigmoid(logit[q]);  id = first arg-max over q;
+//   owner   = id if sigmoid(logit[id]) >= 0.5 and keep[id], else -1
+// One thread per pixel walks the Q logits (coalesced across the wave for every q): one read of the (B,Q,H,W) logits
+// instead of the sigmoid / multiply / arg-max / three compares / two ands / cast chain over that tensor (ten passes).
+// Same arithmetic as the chain (f32 sigmoid 1/(1+exp(-x)), f32 product, first maximum wins), so the ownership map is
+// identical; the per-query boolean masks the reference materialises are `owner == q`.
+__global__ __launch_bounds__(256) void k_mask_owner(const float* __restrict__ logits, const float* __restrict__ score,
+                                                    const uint8_t* __restrict__ keep, int Q, int64_t hw, int32_t* __restrict__ owner) {
+    const int b = blockIdx.y;
+    const int64_t pix = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (pix >= hw) return;
+    const float* L = logits + int64_t(b) * Q * hw + pix;
+    float best = -INFINITY, best_s = 0.f;
+    int id = 0;
+    for (int q = 0; q < Q; ++q) {
+        const float s = 1.0f / (1.0f + expf(-L[int64_t(q) * hw]));
+        const float p = (keep[b * Q + q] ? score[b * Q + q] : -1.0f) * s;
+        if (p > best) {  // strict: the first maximum wins, like torch.argmax
+            best = p;
+            best_s = s;
+            id = q;
+        }
+    }
+    owner[int64_t(b) * hw + pix] = (best_s >= 0.5f && keep[b * Q + id]) ? id : -1;
+}
+
 }  // namespace xm3d
 
 using namespace xm3d;
+
+extern "C" int xm3d_mask_owner(const float* logits, const float* score, const uint8_t* keep, int32_t B, int32_t Q, int64_t hw,
+                               int32_t* owner, void* stream) {
+    XM3D_REQUIRE(B >= 0 && Q >= 1 && hw >= 0 && B <= 65535, "mask_owner: bad sizes B=%d Q=%d hw=%lld", B, Q, (long long)hw);
+    if (B == 0 || hw == 0) return XM3D_OK;
+    XM3D_REQUIRE(logits && score && keep && owner, "mask_owner: null pointer");
+    hipLaunchKernelGGL(k_mask_owner, dim3(unsigned((hw + 255) / 256), unsigned(B)), dim3(256), 0, as_stream(stream), logits, score, keep, Q, hw,
+                       owner);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
 
 extern "C" int xm3d_mask_point_fuse(const uint8_t* masks, int32_t Q, int32_t Hm, int32_t Wm, const int64_t* x,
                                     const int64_t* y, int64_t n, const float* embed, int32_t C, float* feat2d,

@@ -131,6 +131,10 @@ def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, lo
         if own:                         # a model handed in may be trained further: keep its fp32 head weights
             model.cast_head_weights()
     model.enable_dense_graph()
+    import gc
+
+    gc.collect()
+    gc.freeze()  # long-lived model / graph objects out of the cyclic GC's way (a gen-2 pass otherwise stalls the host ~50 ms)
     K = cfg.test_classes
     names = ("fused", "2d", "3d")
     acc = torch.zeros(3, 3, K, device=dev)

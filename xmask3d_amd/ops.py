@@ -446,6 +446,17 @@ def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_w
 
 
 # ---------------------------------------------------------------- 2D->3D fusion
+def mask_owner(logits, score, keep):
+    """logits (B,Q,H,W) f32, score (B,Q) f32, keep (B,Q) bool/u8 -> owner (B,H,W) i32 (query id or -1), see xm3d.h"""
+    _req(logits, torch.float32, "logits", 4)
+    _req(score, torch.float32, "score", 2)
+    keep = keep.to(torch.uint8).contiguous()
+    B, Q, H, W = logits.shape
+    owner = torch.empty((B, H, W), dtype=torch.int32, device=logits.device)
+    check(lib().xm3d_mask_owner(_ptr(logits), _ptr(score), _ptr(keep), B, Q, H * W, _ptr(owner), _stream()), "xm3d_mask_owner")
+    return owner
+
+
 def mask_point_fuse(masks_u8, x_label, y_label, embed):
     """masks (Q,H,W) uint8, x/y (n,) i64, embed (Q,C) f32 -> (feat2d (n,C), count (n,) i32)."""
     _req(masks_u8, torch.uint8, "masks", 3)

@@ -322,6 +322,10 @@ class XMASK3d(nn.Module):
             with torch.cuda.stream(stream):
                 if tail is not None:
                     stream.wait_event(tail)
+                if graphed:
+                    # the sparse front queues up behind this forward's VAE-encoder graph: when both run beside graph C
+                    # at once the front's small kernels starve (30 -> 100 ms at 20 views) and delay the next graph B
+                    stream.wait_stream(g["side"])
                 self.mark("S0", stream)
                 front["pred_3d"], front["cond"], front["binary_scores"] = self.encode_3d(sinput, inds, B)
                 self.mark("S1", stream)
@@ -408,22 +412,16 @@ class XMASK3d(nn.Module):
         cls = outputs["pred_logits"]
         modified = torch.where(is_base, cls.masked_fill(novel_cols, -1e10), cls.masked_fill(base_cols, -1e10))
         scores = F.softmax(modified, dim=-1).max(-1)[0]                        # (B, Q)
-        mask_pred = masks.sigmoid()
         keep = keep_full & (scores > cfg.scores_keep_thresh)
-        # queries not kept must not win the per-pixel arg-max: give them score -1 (kept scores are > 0)
-        prob = torch.where(keep, scores, torch.full_like(scores, -1.0)).view(B, Q, 1, 1) * mask_pred
-        ids = prob.argmax(1)
-        qidx = torch.arange(Q, device=dev).view(1, -1, 1, 1)
-        final = (ids[:, None] == qidx) & (mask_pred >= 0.5) & keep.view(B, Q, 1, 1)
-        final_u8 = final.to(torch.uint8)
+        # pixel ownership in one pass over the logits (xm3d_mask_owner): arg-max over queries of (kept ? score : -1) * sigmoid,
+        # owner = that query where its sigmoid >= 0.5 and it is kept, else -1; the reference's binary masks are owner == q
+        owner = ops.mask_owner(masks.float().contiguous(), scores.float().contiguous(), keep)
+        own_p = owner[vid, x, y].long()                                        # (Np,) query owning each point's pixel, or -1
+        covered = own_p >= 0
         emb = outputs["mask_embed"].float()
-        f2d_l, cnt_l = [], []
-        for i in range(B):
-            sel = slice(offsets[i], offsets[i + 1])
-            f, c = ops.mask_point_fuse(final_u8[i], x[sel], y[sel], emb[i].contiguous())
-            f2d_l.append(f), cnt_l.append(c)
-        feat2d, cnt = torch.cat(f2d_l), torch.cat(cnt_l)
-        mask_3d = final[vid, :, x, y]                                          # (Np, Q)
+        feat2d = torch.where(covered.view(-1, 1), emb[vid, own_p.clamp_min(0)], torch.zeros((), dtype=emb.dtype, device=dev))
+        cnt = covered.to(torch.int32)
+        mask_3d = own_p.view(-1, 1) == torch.arange(Q, device=dev).view(1, -1)  # (Np, Q)
         fused = torch.where((cnt >= 1).view(-1, 1), self.criterion.fuser(feat2d, p3d), p3d)
         pure3d = self.criterion.fc1(p3d)
         emb_open = outputs["mask_embed_clip"]
