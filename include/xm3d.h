@@ -230,9 +230,11 @@ int xm3d_mask_owner(const float* logits, const float* score, const uint8_t* keep
  * counts (2) i64 DEVICE or NULL: {live queries, live references}: only the first counts[0] rows of query and the first
  * counts[1] rows of ref take part (out rows beyond counts[0] are left untouched) - lets the caller order "live" rows
  * first on the device and skip the rest without reading a count back to the host.
+ * ws: NULL or 8*n bytes of device scratch; with it, few-query / many-reference problems are cut into reference slices
+ * merged by a 64-bit atomicMin (same result, better occupancy of the device).
  * ------------------------------------------------------------------------- */
 int xm3d_nearest_index(const float* query, int64_t n, const float* ref, int64_t m, const uint8_t* ref_valid,
-                       const int64_t* counts, int64_t* out, void* stream);
+                       const int64_t* counts, int64_t* out, void* ws, void* stream);
 /* Segmented form (all views of a scene batch in one launch).  pts (n,3) f32 holds, per segment, its query points followed
  * by its reference points; desc (n_seg,4) int64 ON THE DEVICE = {q_off, q_cnt, r_off, r_cnt} per segment; max_queries = a
  * host-side upper bound of q_cnt (sizes the grid).  out[q_off+i] = r_off + index of the nearest reference point of the

@@ -51,7 +51,7 @@ _SIGS = {
     "xm3d_bias_residual_nhwc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "xm3d_attn_mask_bias": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "xm3d_geglu": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
-    "xm3d_nearest_index": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "xm3d_nearest_index": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_nearest_index_segmented": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
     "xm3d_msda_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp]),
     "xm3d_msda_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp, c_vp, c_vp]),

@@ -9,14 +9,28 @@ namespace xm3d {
 
 constexpr int NN_TILE = 1024;
 
+// gridDim.y > 1: the reference range is cut into gridDim.y slices (whole tiles each), one workgroup per (query slab,
+// slice), partial results merged through a 64-bit atomicMin on (distance bits << 32 | index) in `best64` (pre-filled with
+// ~0): the same winner as a sequential scan (smallest distance, lowest index on ties - distances are >= 0, so their bit
+// patterns order like the values), and 4x as many workgroups for the device to balance (80 k queries are only 312 slabs
+// on 256 CUs: 56 CUs got two, the kernel took 2x the per-CU time).
 __global__ __launch_bounds__(256) void k_nearest(const float* __restrict__ q, int64_t n, const float* __restrict__ r, int64_t m,
                                                  const uint8_t* __restrict__ valid, const int64_t* __restrict__ counts,
-                                                 int64_t* __restrict__ out) {
+                                                 int64_t* __restrict__ out, unsigned long long* __restrict__ best64) {
     __shared__ float4 tile[NN_TILE];
     if (counts) {  // device-resident sizes: only the first counts[0] queries / counts[1] references take part
         n = counts[0] < n ? counts[0] : n;
         m = counts[1] < m ? counts[1] : m;
         if (int64_t(blockIdx.x) * blockDim.x >= n) return;  // whole workgroup beyond the live queries
+    }
+    int64_t m_lo = 0;
+    if (gridDim.y > 1) {
+        const int64_t tiles = (m + NN_TILE - 1) / NN_TILE;
+        const int64_t per = (tiles + gridDim.y - 1) / gridDim.y;
+        m_lo = int64_t(blockIdx.y) * per * NN_TILE;
+        const int64_t m_hi = m_lo + per * NN_TILE;
+        m = m_hi < m ? m_hi : m;
+        if (m_lo >= m) return;
     }
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     float qx = 0.f, qy = 0.f, qz = 0.f;
@@ -26,8 +40,8 @@ __global__ __launch_bounds__(256) void k_nearest(const float* __restrict__ q, in
         qz = q[3 * i + 2];
     }
     float best = INFINITY;
-    int64_t besti = 0;
-    for (int64_t t0 = 0; t0 < m; t0 += NN_TILE) {
+    int64_t besti = m_lo;
+    for (int64_t t0 = m_lo; t0 < m; t0 += NN_TILE) {
         const int cnt = int((m - t0 < NN_TILE) ? m - t0 : NN_TILE);
         __syncthreads();
         for (int j = threadIdx.x; j < cnt; j += 256) {
@@ -53,7 +67,18 @@ __global__ __launch_bounds__(256) void k_nearest(const float* __restrict__ q, in
             besti = t0 + tj;
         }
     }
-    if (i < n) out[i] = besti;
+    if (i >= n) return;
+    if (best64)
+        atomicMin(&best64[i], (static_cast<unsigned long long>(__float_as_uint(best)) << 32) | static_cast<unsigned long long>(besti));
+    else
+        out[i] = besti;
+}
+
+__global__ void k_nearest_unpack(const unsigned long long* __restrict__ best64, int64_t n, const int64_t* __restrict__ counts,
+                                 int64_t* __restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (counts && counts[0] < n) n = counts[0];
+    if (i < n) out[i] = int64_t(best64[i] & 0xFFFFFFFFull);
 }
 
 // Segmented form for the per-view hole filling of a whole scene batch in one launch: `pts` holds, for every segment
@@ -123,11 +148,24 @@ extern "C" int xm3d_nearest_index_segmented(const float* pts, const int64_t* des
 }
 
 extern "C" int xm3d_nearest_index(const float* query, int64_t n, const float* ref, int64_t m, const uint8_t* ref_valid,
-                                  const int64_t* counts, int64_t* out, void* stream) {
+                                  const int64_t* counts, int64_t* out, void* ws, void* stream) {
     XM3D_REQUIRE(n >= 0 && m >= 1, "nearest_index: need n >= 0 queries and m >= 1 reference points (n=%lld m=%lld)", (long long)n, (long long)m);
     if (n == 0) return XM3D_OK;
     XM3D_REQUIRE(query && ref && out, "nearest_index: null pointer");
-    hipLaunchKernelGGL(k_nearest, dim3(unsigned((n + 255) / 256)), dim3(256), 0, as_stream(stream), query, n, ref, m, ref_valid, counts, out);
+    XM3D_REQUIRE(m < (1ll << 32), "nearest_index: at most 2^32-1 reference points");
+    hipStream_t s = as_stream(stream);
+    const unsigned slabs = unsigned((n + 255) / 256);
+    // few query slabs per CU and many reference tiles: slice the references (needs the 8*n-byte workspace)
+    const int64_t tiles = (m + NN_TILE - 1) / NN_TILE;
+    const unsigned splits = (ws && slabs < 2048 && tiles >= 8) ? 4u : 1u;
+    if (splits == 1) {
+        hipLaunchKernelGGL(k_nearest, dim3(slabs), dim3(256), 0, s, query, n, ref, m, ref_valid, counts, out, nullptr);
+    } else {
+        unsigned long long* best64 = static_cast<unsigned long long*>(ws);
+        XM3D_HIP(hipMemsetAsync(best64, 0xFF, size_t(n) * 8, s));
+        hipLaunchKernelGGL(k_nearest, dim3(slabs, splits), dim3(256), 0, s, query, n, ref, m, ref_valid, counts, out, best64);
+        hipLaunchKernelGGL(k_nearest_unpack, dim3(slabs), dim3(256), 0, s, best64, n, counts, out);
+    }
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }

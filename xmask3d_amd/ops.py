@@ -506,6 +506,9 @@ def nearest_index(query, ref, ref_valid=None, counts=None):
         out = torch.zeros(query.shape[0], dtype=torch.int64, device=query.device)
     else:
         out = torch.empty(query.shape[0], dtype=torch.int64, device=query.device)
+    ws = None
+    if query.shape[0] < 2048 * 256 and ref.shape[0] >= 8 * 1024:  # few query slabs, many reference tiles: reference slices
+        ws = torch.empty(query.shape[0], dtype=torch.int64, device=query.device)
     check(lib().xm3d_nearest_index(_ptr(query), query.shape[0], _ptr(ref), ref.shape[0], _ptr(ref_valid), _ptr(counts), _ptr(out),
-                                   _stream()), "xm3d_nearest_index")
+                                   _ptr(ws), _stream()), "xm3d_nearest_index")
     return out
