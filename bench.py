@@ -298,7 +298,7 @@ def main():
                                f"{vb} views ({G} scene{'s' if G > 1 else ''}) per forward, seeded random weights", "views_per_scene": n_views, "parallelism": f"dp{world} (scene level, no collective)",
                    "dead_compute": "as reference" if args.faithful_dead_compute else "pruned (SURVEY F7)",
                    "layout": "NCHW" if args.nchw else "channels-last (NHWC) frozen nets",
-                   "schedule": "eager launches" if args.no_graph else "3 HIP graphs per scene + 2-scene software pipeline on side streams"},
+                   "schedule": "eager launches" if args.no_graph else "3 HIP graphs per forward (2 slots), next forward's front software-pipelined on side streams"},
         "roofline": roofline, "roofline_dense_stage": roofline_stage, "cpu_baseline": cpu_baseline,
     }
     print(json.dumps(out))
