@@ -138,14 +138,24 @@ def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, lo
     K = cfg.test_classes
     names = ("fused", "2d", "3d")
     acc = torch.zeros(3, 3, K, device=dev)
-    for s in range(rank, scenes, world):  # DistributedSampler(shuffle=False) partition
-        scene = synthetic.scene_s1(seed=cfg.manual_seed + s)
-        sd = pipeline.SceneOnDevice(scene, dev)
-        np.random.seed(cfg.manual_seed + s)
-        preds = pipeline.infer_scene(model, sd, cfg)
-        gt = synthetic_labels(scene, K, s).to(dev)
-        for j, p in enumerate(preds):
-            acc[j] += torch.stack(metrics.intersection_and_union(p, gt, K, tuple(cfg.test_ignore_label)))
+    mine = list(range(rank, scenes, world))  # DistributedSampler(shuffle=False) partition
+    G = max(1, int(getattr(cfg, "scenes_per_forward", 4)))  # scenes whose views share one forward (pipeline.infer_scenes)
+    chunks = [mine[i:i + G] for i in range(0, len(mine), G)]
+
+    def upload(chunk):
+        scs = [synthetic.scene_s1(seed=cfg.manual_seed + s) for s in chunk]
+        return scs, [pipeline.SceneOnDevice(sc, dev) for sc in scs]
+
+    nxt = upload(chunks[0]) if chunks else None
+    for ci, chunk in enumerate(chunks):
+        scs, sds = nxt
+        nxt = upload(chunks[ci + 1]) if ci + 1 < len(chunks) else None  # resident before this chunk's forward is issued
+        np.random.seed(cfg.manual_seed + chunk[0])
+        results = pipeline.infer_scenes(model, sds, cfg, next_scenes=None if nxt is None else nxt[1])
+        for s, scene, preds in zip(chunk, scs, results):
+            gt = synthetic_labels(scene, K, s).to(dev)
+            for j, p in enumerate(preds):
+                acc[j] += torch.stack(metrics.intersection_and_union(p, gt, K, tuple(cfg.test_ignore_label)))
     if world > 1:
         dist.all_reduce(acc)  # nine SUM all-reduces of the reference (infer.py:717-726) as one
     cs = cfg.category_split
