@@ -115,6 +115,9 @@ int xm3d_spconv_fwd(const float* in, int64_t n_in, int32_t cin, const float* W, 
  * (ksplit*n_out*cout f32) and are reduced in fixed order with the epilogue fused (deterministic). */
 int xm3d_rulebook_tiles(const int32_t* nbr, const int32_t* order, int64_t n_out, int32_t K, int32_t* tsrc,
                         uint8_t* tdst, int32_t* tcnt, void* stream);
+/* Output channels one workgroup of xm3d_spconv_fwd_tiles owns for a (cin, cout) layer (32; 48 only under the experiment
+ * switch XM3D_SPCONV_CT=48): callers size the split-K factor from the resulting workgroup count. */
+int xm3d_spconv_tile_channels(int32_t cin, int32_t cout);
 int xm3d_spconv_fwd_tiles(const float* in, int64_t n_in, int32_t cin, const float* Wp, int32_t K, int32_t cout,
                           const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order,
                           int64_t n_out, const float* scale, const float* shift, const float* residual,

@@ -19,6 +19,8 @@
 //
 // Replaces ME.MinkowskiConvolution(+Transpose) and the BN/ReLU/residual tail of ME's BasicBlock
 // (call sites: models/modeling/meta_arch/mink_unet.py:47-109,118-178, resnet_base.py:64-96).
+#include <cstdlib>
+
 #include "common.h"
 
 namespace xm3d {
@@ -225,17 +227,19 @@ __global__ __launch_bounds__(256) void k_build_tiles(const int32_t* __restrict__
     if (threadIdx.x == 0) tcnt[int64_t(tile) * K + k] = wcnt[0] + wcnt[1] + wcnt[2] + wcnt[3];
 }
 
-template <int ST_>
+// NTT = 16-wide output-channel tiles per workgroup (2 -> 32 channels, 3 -> 48): a wider tile gathers every input row
+// fewer times (cout / (16*NTT) workgroups share a row tile) at the price of a larger LDS accumulator.
+template <int ST_, int NTT>
 struct __attribute__((aligned(16))) TileLds {
-    float acc[TROWS][ACC_LD];
-    float w[2][ST_ * NT * 256];
+    float acc[TROWS][16 * NTT + 4];
+    float w[2][ST_ * NTT * 256];
     int cnt[128];  // pairs per offset of this tile (K <= 125)
 };
 
 // Per-wave software pipeline over the wave's own tile sequence (which spans steps):
 //   stage A: pair indices (tsrc/tdst) of tile i+3      stage B: row gathers of tile i+2      stage C: MFMAs of tile i
 // so the count -> index -> gather chain of dependent L2 round trips is off the critical path.
-template <int ST_>
+template <int ST_, int NTT = NT>
 __global__ __launch_bounds__(256, 2) void k_spconv_tiles(const float* __restrict__ in, int cin, const float* __restrict__ Wp,
                                                           int K, int cout, const int32_t* __restrict__ tsrc,
                                                           const uint8_t* __restrict__ tdst, const int32_t* __restrict__ tcnt,
@@ -243,20 +247,22 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tiles(const float* __restrict
                                                           const float* __restrict__ scale, const float* __restrict__ shift,
                                                           const float* __restrict__ residual, int relu,
                                                           float* __restrict__ out, int ksplit, float* __restrict__ slab) {
-    __shared__ TileLds<ST_> lds;
-    constexpr int NW = ST_ * NT / 4;  // float4 weight loads per thread per step
+    __shared__ TileLds<ST_, NTT> lds;
+    constexpr int CTT = 16 * NTT, ACCLD = CTT + 4;
+    constexpr int TOT4 = ST_ * NTT * 64;          // float4 of weights per step
+    constexpr int NW = (TOT4 + 255) / 256;        // float4 weight loads per thread per step
     const int kz = blockIdx.z;                              // split-K: this workgroup handles offsets kz, kz+ksplit, ...
     const int nk = (K - kz + ksplit - 1) / ksplit;
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
     const int p16 = lane & 15, kq = lane >> 4;
     const int tile = blockIdx.x;
-    const int ct0 = blockIdx.y * CT;
+    const int ct0 = blockIdx.y * CTT;
     const int NS = cout / 16, CS = cin / 16;
     const int nchunk = cin / (16 * ST_);
     const int nsteps = nk * nchunk;
     const int64_t tbase = int64_t(tile) * K;
 
-    for (int c = tid; c < TROWS * ACC_LD; c += 256) (&lds.acc[0][0])[c] = 0.f;
+    for (int c = tid; c < TROWS * ACCLD; c += 256) (&lds.acc[0][0])[c] = 0.f;
     if (tid < nk) lds.cnt[tid] = tcnt[tbase + kz + tid * ksplit];
 
     f32x4 wreg[NW];
@@ -265,15 +271,17 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tiles(const float* __restrict
         const int k = kz + kk * ksplit;
 #pragma unroll
         for (int j = 0; j < NW; ++j) {
-            const int f = j * 256 + tid;  // float4 index inside the chunk: ST segments of 128 float4
-            const int s = f >> 7, within = f & 127;
+            const int f = j * 256 + tid;  // float4 index inside the chunk: ST segments of NTT*64 float4
+            if (TOT4 % 256 != 0 && f >= TOT4) continue;
+            const int s = f / (NTT * 64), within = f % (NTT * 64);
             const int64_t g = ((int64_t(k) * CS + cc * ST_ + s) * NS + ct0 / 16) * 256 + within * 4;
             wreg[j] = *reinterpret_cast<const f32x4*>(Wp + g);
         }
     };
     auto store_w = [&](int buf) {
 #pragma unroll
-        for (int j = 0; j < NW; ++j) *reinterpret_cast<f32x4*>(&lds.w[buf][(j * 256 + tid) * 4]) = wreg[j];
+        for (int j = 0; j < NW; ++j)
+            if (TOT4 % 256 == 0 || j * 256 + tid < TOT4) *reinterpret_cast<f32x4*>(&lds.w[buf][(j * 256 + tid) * 4]) = wreg[j];
     };
     if (nsteps > 0) {
         load_w(0);
@@ -338,11 +346,11 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tiles(const float* __restrict
             load_idx(r3, s3, d3);   // stage A for tile i+3
             gather(r2, s2, x2);     // stage B for tile i+2
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {  // stage C
+            for (int n = 0; n < NTT; ++n) {  // stage C
                 f32x4 d = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int s = 0; s < ST_; ++s) {
-                    const f32x4 w = *reinterpret_cast<const f32x4*>(&lds.w[cur][(s * NT + n) * 256 + lane * 4]);
+                    const f32x4 w = *reinterpret_cast<const f32x4*>(&lds.w[cur][(s * NTT + n) * 256 + lane * 4]);
                     d = __builtin_amdgcn_mfma_f32_16x16x4f32(w[0], x0[s][0], d, 0, 0, 0);
                     d = __builtin_amdgcn_mfma_f32_16x16x4f32(w[1], x0[s][1], d, 0, 0, 0);
                     d = __builtin_amdgcn_mfma_f32_16x16x4f32(w[2], x0[s][2], d, 0, 0, 0);
@@ -372,12 +380,13 @@ __global__ __launch_bounds__(256, 2) void k_spconv_tiles(const float* __restrict
         __syncthreads();
         cur ^= 1;
     }
-    // epilogue: 8 lanes x float4 per 32-channel row, 32 rows per pass
-    const int rsub = tid >> 3, c4 = (tid & 7) * 4;
-    for (int r = 0; r < TROWS; r += 32) {
+    // epilogue: CTT/4 lanes x float4 per row, 256/(CTT/4) rows per pass
+    constexpr int LPR = CTT / 4, RPP = 256 / LPR;
+    const int rsub = tid / LPR, c4 = (tid % LPR) * 4;
+    for (int r = 0; r < TROWS; r += RPP) {
         const int lr = r + rsub;
         const int64_t sl = int64_t(tile) * TROWS + lr;
-        if (sl >= n_out) continue;
+        if (rsub >= RPP || lr >= TROWS || sl >= n_out) continue;
         const int64_t grow = order ? order[sl] : sl;
         f32x4 v = *reinterpret_cast<const f32x4*>(&lds.acc[lr][c4]);
         const int c = ct0 + c4;
@@ -589,6 +598,18 @@ extern "C" int xm3d_rulebook_tiles(const int32_t* nbr, const int32_t* order, int
     return XM3D_OK;
 }
 
+// output channels per workgroup of xm3d_spconv_fwd_tiles for a (cin, cout) layer.  32 everywhere: the 48-wide variant
+// (k_spconv_tiles<6, 3>, one gather per 48 instead of 32 output channels) measured 343 us against 255 us on the 96 -> 96
+// layer of the roofline bench - one workgroup per CU instead of two costs more than the saved gathers (and 48-deep steps
+// with two workgroups: 366 us).  XM3D_SPCONV_CT=48 selects it for experiments (cin % 96 == 0, cout % 48 == 0 layers).
+extern "C" int xm3d_spconv_tile_channels(int32_t cin, int32_t cout) {
+    static const int forced = [] {
+        const char* e = getenv("XM3D_SPCONV_CT");
+        return e ? atoi(e) : 0;
+    }();
+    return (forced == 48 && cin % 96 == 0 && cout % 48 == 0 && cout % 32 == 0) ? 48 : 32;
+}
+
 extern "C" int xm3d_spconv_fwd_tiles(const float* in, int64_t n_in, int32_t cin, const float* Wp, int32_t K, int32_t cout,
                                      const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order,
                                      int64_t n_out, const float* scale, const float* shift, const float* residual,
@@ -601,12 +622,25 @@ extern "C" int xm3d_spconv_fwd_tiles(const float* in, int64_t n_in, int32_t cin,
                    reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0,
                  "spconv_fwd_tiles: tensors must be 16-byte aligned");
     XM3D_REQUIRE(ksplit >= 1 && ksplit <= K && (ksplit == 1 || slab), "spconv_fwd_tiles: ksplit=%d needs 1..K and a slab", ksplit);
-    dim3 grid((n_out + TROWS - 1) / TROWS, cout / CT, ksplit);
     hipStream_t s = as_stream(stream);
+    XM3D_REQUIRE(K <= 128, "spconv_fwd_tiles: K=%d > 128", K);
+    if (xm3d_spconv_tile_channels(cin, cout) == 48) {  // 48-channel output tiles: every input row gathered cout/48 times
+        dim3 grid48((n_out + TROWS - 1) / TROWS, cout / 48, ksplit);
+        hipLaunchKernelGGL((k_spconv_tiles<6, 3>), grid48, dim3(256), 0, s, in, cin, Wp, K, cout, tsrc, tdst, tcnt, order, n_out, scale,
+                           shift, residual, relu, out, ksplit, slab);
+        if (ksplit > 1) {
+            const int64_t n4 = n_out * cout / 4;
+            int64_t blocks = (n4 + 255) / 256;
+            if (blocks > 2048) blocks = 2048;
+            hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out);
+        }
+        XM3D_LAUNCH_CHECK();
+        return XM3D_OK;
+    }
+    dim3 grid((n_out + TROWS - 1) / TROWS, cout / CT, ksplit);
 #define XM3D_TILES(ST_)                                                                                                 \
     hipLaunchKernelGGL(k_spconv_tiles<ST_>, grid, dim3(256), 0, s, in, cin, Wp, K, cout, tsrc, tdst, tcnt, order, n_out, \
                        scale, shift, residual, relu, out, ksplit, slab)
-    XM3D_REQUIRE(K <= 128, "spconv_fwd_tiles: K=%d > 128", K);
     if (cin % 128 == 0) XM3D_TILES(8);
     else if (cin % 96 == 0) XM3D_TILES(6);
     else if (cin % 64 == 0) XM3D_TILES(4);

@@ -244,7 +244,7 @@ def spconv_fwd(feats, kernel, nbr, n_out, order=None, scale=None, shift=None, re
             raise RuntimeError("ALGO_TILES needs the tiled rulebook (CoordinateManager.tiles)")
         tsrc, tdst, tcnt = tiles
         if ksplit is None:
-            wgs = ((n_out + 255) // 256) * (cout // 32)
+            wgs = ((n_out + 255) // 256) * (cout // lib().xm3d_spconv_tile_channels(cin, cout))
             ksplit = 1 if wgs >= 256 else max(1, min(K, 768 // max(wgs, 1)))
         slab = torch.empty((ksplit, n_out, cout), dtype=torch.float32, device=feats.device) if ksplit > 1 else None
         check(lib().xm3d_spconv_fwd_tiles(_ptr(feats), feats.shape[0], cin, _ptr(w), K, cout, _ptr(tsrc), _ptr(tdst), _ptr(tcnt),
