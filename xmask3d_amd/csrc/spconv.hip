@@ -240,7 +240,7 @@ struct __attribute__((aligned(16))) TileLds {
 //   stage A: pair indices (tsrc/tdst) of tile i+3      stage B: row gathers of tile i+2      stage C: MFMAs of tile i
 // so the count -> index -> gather chain of dependent L2 round trips is off the critical path.
 template <int ST_, int NTT = NT>
-__global__ __launch_bounds__(256, 2) void k_spconv_tiles(const float* __restrict__ in, int cin, const float* __restrict__ Wp,
+__global__ __launch_bounds__(256, (NTT <= 2 ? 2 : 1)) void k_spconv_tiles(const float* __restrict__ in, int cin, const float* __restrict__ Wp,
                                                           int K, int cout, const int32_t* __restrict__ tsrc,
                                                           const uint8_t* __restrict__ tdst, const int32_t* __restrict__ tcnt,
                                                           const int32_t* __restrict__ order, int64_t n_out,
