@@ -437,7 +437,7 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
             from . import ops
 
             if ops.attn_mask_bias_supported(outputs_mask.shape, attn_mask_target_size):
-                qdt = torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else torch.float32
+                qdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else torch.float32
                 if qdt in (torch.float32, torch.bfloat16):  # one launch: shrink, threshold, empty-mask rule, additive bias
                     return outputs_class, outputs_mask, ops.attn_mask_bias(outputs_mask, attn_mask_target_size, qdt), extra
         attn_mask = bilinear_down(outputs_mask, attn_mask_target_size)

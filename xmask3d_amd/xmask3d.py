@@ -189,19 +189,22 @@ class XMASK3d(nn.Module):
         img = img.to(imp_condition_input.device).float()
         return self.backbone(self.normalize_images(img), imp_condition_input, encoded, fork_stream)
 
-    def dense_heads(self, img, feature):
-        """Second half (rows a13-a17): pixel decoder, transformer decoder, category logits, mask-CLIP.  Many small
-        dependent kernels: latency-bound, leaves most of the device idle."""
-        dev = img.device
-        img = img.float()
+    def _decode_heads(self, img, feature):
+        """pixel decoder + transformer decoder on the projected features -> decoder outputs (+ the [0,1] images mask-CLIP reads)"""
         low = self.dense_dtype != torch.float32 and self.low_precision_heads and not torch.is_grad_enabled()
         # bf16 mode: GEMMs of the pixel / transformer decoder run in bf16 too (the reference keeps them fp32; sampling in
         # xm3d_msda_forward, LayerNorm statistics and the mask logits stay f32)
-        with torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=low):
+        with torch.autocast(device_type=img.device.type, dtype=torch.bfloat16, enabled=low):
             outputs = self.sem_seg_head({k: v.float() for k, v in feature.items()})
         for k in ("pred_masks", "mask_embed", "mask_pooled_features"):
             outputs[k] = outputs[k].float()
-        outputs["images"] = img / 255.0
+        outputs["images"] = img.float() / 255.0
+        return outputs
+
+    def dense_heads(self, img, feature):
+        """Second half (rows a13-a17): pixel decoder, transformer decoder, category logits, mask-CLIP.  Many small
+        dependent kernels: latency-bound, leaves most of the device idle."""
+        outputs = self._decode_heads(img, feature)
         outputs.update(self.category_head(outputs))
         outputs["pred_logits"] = self.cal_pred_logits(outputs)
         clip_embed = self.clip_head(outputs["images"], outputs["pred_masks"])  # casts to the visual tower's dtype inside
@@ -209,27 +212,15 @@ class XMASK3d(nn.Module):
         return outputs
 
     def encode_2d(self, img, imp_condition_input, encoded=None, fork_stream=None):
-        """img (B,3,H,W) 0..255 -> decoder outputs (training: + nothing else; the losses add the category head themselves)."""
+        """img (B,3,H,W) 0..255 -> decoder outputs (the training forward adds category head and losses itself)."""
         img = img.to(imp_condition_input.device)
-        feature = self.dense_features(img, imp_condition_input, encoded, fork_stream)
-        dev = imp_condition_input.device
-        low = self.dense_dtype != torch.float32 and self.low_precision_heads and not torch.is_grad_enabled()
-        with torch.autocast(device_type=dev.type, dtype=torch.bfloat16, enabled=low):
-            outputs = self.sem_seg_head({k: v.float() for k, v in feature.items()})
-        for k in ("pred_masks", "mask_embed", "mask_pooled_features"):
-            outputs[k] = outputs[k].float()
-        outputs["images"] = img.float() / 255.0
-        return outputs
+        return self._decode_heads(img, self.dense_features(img, imp_condition_input, encoded, fork_stream))
 
     def dense_forward(self, img, cond, encoded=None, fork_stream=None):
-        """The static-shape part of the eval forward (rows a8-a17): SD feature extractor, projections, pixel +
-        transformer decoder, category logits, mask-CLIP.  img (B,3,H,W) 0..255 on device, cond (B,768)."""
-        outputs = self.encode_2d(img, cond, encoded, fork_stream)
-        outputs.update(self.category_head(outputs))
-        outputs["pred_logits"] = self.cal_pred_logits(outputs)
-        clip_embed = self.clip_head(outputs["images"], outputs["pred_masks"])  # casts to the visual tower's dtype inside
-        outputs["mask_embed_clip"] = clip_embed["mask_embed_clip"].float()
-        return outputs
+        """The static-shape part of the eval forward (rows a8-a17) in one call: dense_features + dense_heads.
+        img (B,3,H,W) 0..255 on device, cond (B,768)."""
+        img = img.to(cond.device)
+        return self.dense_heads(img, self.dense_features(img, cond, encoded, fork_stream))
 
     def enable_dense_graph(self, on=True, slots=2):
         """Replay the static-shape dense branch as one HIP graph per input shape (inference only): ~2000 launch-bound
