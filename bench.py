@@ -91,6 +91,60 @@ def spconv_roofline(dev):
             "gather_scatter_GBps": gs_bytes / (ms * 1e-3) / 1e9}
 
 
+def train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log):
+    """SURVEY 8d metric (ii): training iterations per second at one view per GPU (BASELINE config 3: global batch = one
+    scene per GPU), forward + 37 weighted losses + backward + AdamW, gradients all-reduced by DDP when world > 1."""
+    import torch.distributed as dist
+    from xmask3d_amd import me_compat as ME, pipeline
+    from xmask3d_amd.driver import build_optimizer
+    from xmask3d_amd.xmask3d import XMASK3d
+
+    tdt = torch.bfloat16 if args.train_dtype == "bf16" else torch.float32
+    torch.manual_seed(cfg.manual_seed)
+    model = XMASK3d(cfg).to(dev).set_dense_dtype(tdt).train()
+    model.backbone.feature_extractor.ldm_extractor.enable_train_graph()
+    if world > 1:
+        ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)  # per-GPU batch < 4 (run/train.py:185-187)
+        torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)
+    opt = build_optimizer(model, cfg)
+    nv = len(sd.views)
+
+    def it(i):
+        batch = pipeline.build_train_batch(sd, [(i + rank) % nv], voxelizer, seed=cfg.manual_seed + i)
+        losses, _ = model(batch)
+        loss = sum(losses.values())
+        opt.zero_grad(set_to_none=True)
+        loss.backward()
+        opt.step()
+        return loss
+
+    for i in range(2):
+        it(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.train_steps):
+        last = it(i + 2)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if not bool(torch.isfinite(last.detach())):
+        raise SystemExit("bench: training loss is not finite")
+    log(f"training leg: {args.train_steps} iterations in {dt:.3f} s")
+    return {"iters_per_s": args.train_steps / dt, "ms_per_iter": dt / args.train_steps * 1e3, "steps": args.train_steps,
+            "views_per_gpu": 1, "global_batch_views": world, "frozen_nets_dtype": args.train_dtype,
+            "scope": "forward + 37 weighted losses (CPU Hungarian matching like the reference) + backward + AdamW; frozen UNet "
+                     "forward/backward replayed as HIP graphs; DDP gradient all-reduce + MinkowskiSyncBatchNorm when n_gpus > 1"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -102,6 +156,9 @@ def main():
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find through the shipped find-db)")
     ap.add_argument("--scenes-per-forward", type=int, default=4,
                     help="scenes whose views share one forward (views are independent until the vote); 1 = one scene per forward")
+    ap.add_argument("--train-steps", type=int, default=0,
+                    help="also time this many training iterations (1 view per GPU, DDP when --gpus > 1) and report them under \"train\"")
+    ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the frozen nets in the training leg")
     ap.add_argument("--nchw", action="store_true", help="keep NCHW activations in the frozen conv nets (default: channels-last)")
     ap.add_argument("--no-graph", action="store_true", help="launch the dense branch eagerly instead of replaying a HIP graph")
     ap.add_argument("--faithful-dead-compute", action="store_true", help="also run what the reference computes and discards")
@@ -232,6 +289,7 @@ def main():
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+    train = train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log) if args.train_steps > 0 else None
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -299,7 +357,7 @@ def main():
                    "dead_compute": "as reference" if args.faithful_dead_compute else "pruned (SURVEY F7)",
                    "layout": "NCHW" if args.nchw else "channels-last (NHWC) frozen nets",
                    "schedule": "eager launches" if args.no_graph else "3 HIP graphs per forward (2 slots), next forward's front software-pipelined on side streams"},
-        "roofline": roofline, "roofline_dense_stage": roofline_stage, "cpu_baseline": cpu_baseline,
+        "roofline": roofline, "roofline_dense_stage": roofline_stage, "cpu_baseline": cpu_baseline, "train": train,
     }
     print(json.dumps(out))
     if world > 1:
