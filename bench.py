@@ -91,6 +91,14 @@ def spconv_roofline(dev):
             "gather_scatter_GBps": gs_bytes / (ms * 1e-3) / 1e9}
 
 
+def balanced_groups(n_scenes, per_forward):
+    """n scenes in ceil(n / per_forward) forwards, as even as possible (5 scenes at 4 per forward -> 3 + 2, not 4 + 1)"""
+    if n_scenes <= 0:
+        return []
+    ng = -(-n_scenes // per_forward)
+    return [n_scenes // ng + (1 if i < n_scenes % ng else 0) for i in range(ng)]
+
+
 def train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log):
     """SURVEY 8d metric (ii): training iterations per second at one view per GPU (BASELINE config 3: global batch = one
     scene per GPU), forward + 37 weighted losses + backward + AdamW, gradients all-reduced by DDP when world > 1."""
@@ -230,9 +238,8 @@ def main():
 
     G = 1 if (args.no_graph or args.views_per_batch) else max(1, args.scenes_per_forward)
 
-    def group_sizes(n_scenes):  # ceil(n/G) groups, as even as possible (5 scenes at G=4 -> 3+2, not 4+1)
-        ng = -(-n_scenes // G)
-        return [n_scenes // ng + (1 if i < n_scenes % ng else 0) for i in range(ng)]
+    def group_sizes(n_scenes):
+        return balanced_groups(n_scenes, G)
 
     def run(n_scenes):
         """n_scenes steps (one step = one scene).  Scenes go through the model in groups of G (all views of the group in

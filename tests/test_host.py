@@ -49,3 +49,46 @@ def test_bilinear_down_is_bit_identical_to_interpolate():
         for t in (16, 32, 64):
             assert torch.equal(bilinear_down(x, (t, t)), F.interpolate(x, size=(t, t), mode="bilinear", align_corners=False))
         assert torch.equal(bilinear_down(x, (48, 48)), F.interpolate(x, size=(48, 48), mode="bilinear", align_corners=False))  # fallback
+
+
+def test_bench_scene_groups_are_balanced():
+    import bench
+
+    assert bench.balanced_groups(16, 4) == [4, 4, 4, 4]
+    assert bench.balanced_groups(5, 4) == [3, 2] and bench.balanced_groups(1, 4) == [1] and bench.balanced_groups(0, 4) == []
+    for n in range(1, 40):
+        for g in (1, 2, 4):
+            sizes = bench.balanced_groups(n, g)
+            assert sum(sizes) == n and max(sizes) <= g and max(sizes) - min(sizes) <= 1
+
+
+def test_gate_equals_the_reference_formula():
+    """pipeline._gate (masked_fill + where) == binary_pred * logits_base + (1 - binary_pred) * logits_novel (infer.py:489-507)"""
+    import torch
+    from xmask3d_amd import pipeline
+
+    torch.manual_seed(0)
+    logits = torch.randn(200, 19)
+    binary = (torch.rand(200, 1) > 0.5).long()
+    base, novel = [0, 1, 2, 5, 7, 8, 9, 10, 11, 12, 13, 14, 15, 17, 18], [3, 4, 6, 16]
+    bm, nm = torch.zeros(19, dtype=torch.bool), torch.zeros(19, dtype=torch.bool)
+    bm[base], nm[novel] = True, True
+    lb, ln = logits.clone(), logits.clone()
+    ln[:, base] = -1e10
+    lb[:, novel] = -1e10
+    assert torch.equal(pipeline._gate(logits, binary, bm, nm), binary * lb + (1 - binary) * ln)
+
+
+def test_scene_tables_concatenate_the_views():
+    import torch
+    from xmask3d_amd import pipeline, synthetic
+
+    sd = pipeline.SceneOnDevice(synthetic.scene_s0(), torch.device("cpu"))
+    assert torch.equal(sd.idx_all, torch.cat([v["idx"] for v in sd.views]))
+    assert torch.equal(sd.x_all, torch.cat([v["x"] for v in sd.views])) and torch.equal(sd.y_all, torch.cat([v["y"] for v in sd.views]))
+    off = 0
+    for i, v in enumerate(sd.views):
+        n = v["idx"].shape[0]
+        assert bool((sd.view_all[off:off + n] == i).all())
+        off += n
+    assert off == sd.view_all.shape[0]
