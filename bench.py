@@ -114,7 +114,7 @@ def train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log):
     if world > 1:
         ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)  # per-GPU batch < 4 (run/train.py:185-187)
         torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=False)
     opt = build_optimizer(model, cfg)
     nv = len(sd.views)
 

@@ -209,6 +209,15 @@ int xm3d_msda_backward(const float* value, const int64_t* spatial_shapes, const 
                        const float* loc, const float* attn, const float* grad_out, int32_t B, int32_t S,
                        int32_t H, int32_t D, int32_t L, int32_t Lq, int32_t P, float* grad_value,
                        float* grad_loc, float* grad_attn, void* stream);
+/* double instantiation: the reference dispatches the op over float AND double (AT_DISPATCH_FLOATING_TYPES,
+ * cuda/ms_deform_attn_cuda.cu:64,134) and its own gradcheck runs in double (ops/test.py:66-81). */
+int xm3d_msda_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                          const double* loc, const double* attn, int32_t B, int32_t S, int32_t H, int32_t D,
+                          int32_t L, int32_t Lq, int32_t P, double* out, void* stream);
+int xm3d_msda_backward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                           const double* loc, const double* attn, const double* grad_out, int32_t B, int32_t S,
+                           int32_t H, int32_t D, int32_t L, int32_t Lq, int32_t P, double* grad_value,
+                           double* grad_loc, double* grad_attn, void* stream);
 
 /* ---------------------------------------------------------------------------
  * 2D->3D mask fusion epilogue (replaces the per-query Python loops of

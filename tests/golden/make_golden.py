@@ -14,6 +14,13 @@ What is captured (reference file -> fixture):
   models/utils/fusion_util.py, mapping_util.py              -> mapping.npz
   models/modeling/diffusion/gaussian_diffusion.py           -> diffusion.npz
   util/config.py + config/scannet/*.yaml                    -> config_b15n4.json
+  models/modeling/meta_arch/{mink_unet,resnet_base,pc_processor}.py
+      built through xmask3d_amd.me_compat.install_as_minkowski_engine()   -> seam_minkunet_keys.json
+      (state_dict key -> shape of PC_Processor(34C) / PC_Binary_Processor(18A))
+      and RUN (the reference's own forward code) on oracle/me_cpu_stub.py -> seam_minkunet_forward.npz
+  .../pixel_decoder/ops/functions/ms_deform_attn_func.py + ops/modules/ms_deform_attn.py
+      imported with xmask3d_amd.msda.install_as_msda(): the positional calls the reference's
+      MSDeformAttnFunction makes into the extension module, recorded -> seam_msda_call.npz / .json
 """
 import collections
 import collections.abc
@@ -201,7 +208,111 @@ def gen_config():
     print("wrote config_b15n4.json")
 
 
+def _load_ref_meta_arch(tag):
+    """import the reference's mink_unet / resnet_base / pc_processor files under a private package name (their package
+    __init__ chain needs detectron2); whatever module is registered as ``MinkowskiEngine`` at this moment is what they bind"""
+    import importlib.util
+    import types
+
+    base = os.path.join(REF, "models/modeling/meta_arch")
+    pkg = types.ModuleType(tag)
+    pkg.__path__ = [base]
+    sys.modules[tag] = pkg
+    mods = {}
+    for name in ("resnet_base", "mink_unet", "pc_processor"):
+        spec = importlib.util.spec_from_file_location(f"{tag}.{name}", os.path.join(base, name + ".py"))
+        m = importlib.util.module_from_spec(spec)
+        m.__package__ = tag
+        sys.modules[f"{tag}.{name}"] = m
+        spec.loader.exec_module(m)
+        mods[name] = m
+    return mods
+
+
+def gen_seams():
+    sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+    from oracle import me_cpu_stub
+    from xmask3d_amd import me_compat, msda
+
+    # (1) the reference's model files built on the PRODUCT's ME seam: parameter names / shapes it expects
+    me_compat.install_as_minkowski_engine()
+    ref = _load_ref_meta_arch("ref_meta_product")
+    nets = {"pc_decoder": ref["pc_processor"].PC_Processor(arch_3d="MinkUNet34C"),
+            "pc_binary_head": ref["pc_processor"].PC_Binary_Processor(arch_3d="MinkUNet18A")}
+    keys = {n: {k: list(v.shape) for k, v in m.state_dict().items()} for n, m in nets.items()}
+    with open(os.path.join(HERE, "seam_minkunet_keys.json"), "w") as f:
+        json.dump(keys, f, indent=0, sort_keys=True)
+    print("wrote seam_minkunet_keys.json", {n: len(k) for n, k in keys.items()})
+
+    # (2) the reference's forward code executed on the CPU stand-in of the ME ops, closed-form parameters
+    me_cpu_stub.install()
+    ref = _load_ref_meta_arch("ref_meta_cpu")
+    coords, feats = me_cpu_stub.seam_cloud()
+    arrs = dict(coords=coords, feats=feats)
+    for name, cls, arch in (("pc_decoder", "PC_Processor", "MinkUNet34C"), ("pc_binary_head", "PC_Binary_Processor", "MinkUNet18A")):
+        net = getattr(ref["pc_processor"], cls)(arch_3d=arch).eval()
+        assert {k: list(v.shape) for k, v in net.state_dict().items()} == keys[name]
+        net.load_state_dict(me_cpu_stub.closed_form_state(keys[name]))
+        with torch.no_grad():
+            out = net(me_cpu_stub.SparseTensor(torch.from_numpy(feats), coords))
+        if name == "pc_decoder":
+            arrs.update(implicit_x=out[0].numpy(), x_rows=out[1][::8].numpy(), idx=out[2].numpy())
+        else:
+            arrs.update(binary=out.numpy())
+    save("seam_minkunet_forward.npz", **arrs)
+
+    # (3) the MSDeformAttn extension seam: what the reference's Function passes, positionally, and what it expects back
+    sys.path.insert(0, os.path.join(REF, "third_party/Mask2Former/mask2former/modeling/pixel_decoder"))
+    calls = []
+
+    class Recorder:
+        """stands where the compiled extension would be; answers with the reference's own CPU formulation"""
+
+        @staticmethod
+        def ms_deform_attn_forward(*args):
+            calls.append(("ms_deform_attn_forward", args))
+            return core(args[0], args[1], args[3], args[4])
+
+        @staticmethod
+        def ms_deform_attn_backward(*args):
+            calls.append(("ms_deform_attn_backward", args))
+            v, l, w = (args[i].detach().clone().requires_grad_(True) for i in (0, 3, 4))
+            with torch.enable_grad():
+                core(v, args[1], l, w).backward(args[5])
+            return v.grad, l.grad, w.grad
+
+    sys.modules["MultiScaleDeformableAttention"] = Recorder
+    for m in [k for k in sys.modules if k == "ops" or k.startswith("ops.")]:
+        del sys.modules[m]
+    from ops.functions.ms_deform_attn_func import MSDeformAttnFunction, ms_deform_attn_core_pytorch as core
+    from ops.modules.ms_deform_attn import MSDeformAttn as RefModule
+
+    torch.manual_seed(21)
+    shapes = torch.as_tensor([(5, 7), (3, 4)], dtype=torch.long)
+    lsi = torch.cat((shapes.new_zeros((1,)), shapes.prod(1).cumsum(0)[:-1]))
+    S = int(shapes.prod(1).sum())
+    value = torch.rand(2, S, 4, 8, requires_grad=True)
+    loc = (torch.rand(2, 9, 4, 2, 3, 2) * 1.2 - 0.1).requires_grad_(True)
+    w = torch.rand(2, 9, 4, 2, 3)
+    w = (w / w.sum((-1, -2), keepdim=True)).requires_grad_(True)
+    out = MSDeformAttnFunction.apply(value, shapes, lsi, loc, w, 2)
+    go = torch.randn_like(out)
+    out.backward(go)
+    sig = {name: [("tensor", str(a.dtype).replace("torch.", ""), list(a.shape)) if torch.is_tensor(a) else ("int", int(a)) for a in args]
+           for name, args in calls}
+    assert set(sig) == {"ms_deform_attn_forward", "ms_deform_attn_backward"}
+    refmod = RefModule(d_model=256, n_levels=3, n_heads=8, n_points=4)
+    with open(os.path.join(HERE, "seam_msda_call.json"), "w") as f:
+        json.dump({"calls": sig, "module_state": {k: list(v.shape) for k, v in refmod.state_dict().items()},
+                   "module_im2col_step": refmod.im2col_step}, f, indent=0, sort_keys=True)
+    save("seam_msda_call.npz", value=value.detach().numpy(), shapes=shapes.numpy(), level_start=lsi.numpy(), loc=loc.detach().numpy(),
+         w=w.detach().numpy(), im2col_step=np.int64(2), out=out.detach().numpy(), grad_out=go.numpy(),
+         g_value=value.grad.numpy(), g_loc=loc.grad.numpy(), g_w=w.grad.numpy())
+    # and the product module drops into the same import name
+    assert msda.install_as_msda() is sys.modules["MultiScaleDeformableAttention"]
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["voxel", "msda", "fuser", "mapping", "diffusion", "config"]
+    which = sys.argv[1:] or ["voxel", "msda", "fuser", "mapping", "diffusion", "config", "seams"]
     for w in which:
         globals()["gen_" + w]()

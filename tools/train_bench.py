@@ -26,7 +26,7 @@ if "graph" in sys.argv[3:]:
     model.backbone.feature_extractor.ldm_extractor.enable_train_graph()
 if world > 1:
     ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)      # per-GPU batch < 4 (run/train.py:185-187)
-    model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=True)
+    model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False)
 core = model.module if world > 1 else model
 # two parameter groups as run/train.py:152-169
 p3d = [p for n, p in core.named_parameters() if p.requires_grad and ("pc_decoder" in n or "pc_binary_head" in n)]

@@ -56,6 +56,8 @@ _SIGS = {
     "xm3d_nearest_index_segmented": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),
     "xm3d_msda_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp]),
     "xm3d_msda_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp, c_vp, c_vp]),
+    "xm3d_msda_forward_f64": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp]),
+    "xm3d_msda_backward_f64": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp, c_vp, c_vp]),
     "xm3d_mask_point_fuse": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp, c_i64, c_vp, c_i32, c_vp, c_vp, c_vp]),
     "xm3d_mask_owner": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i32, c_i64, c_vp, c_vp]),
 }

@@ -12,52 +12,62 @@
 
 namespace xm3d {
 
-template <int V>
+// T = float or double: the reference op is instantiated for both (AT_DISPATCH_FLOATING_TYPES,
+// ops/src/cuda/ms_deform_attn_cuda.cu:64,134; its gradcheck runs in double, ops/test.py:66-81).
+template <typename T, int V>
 struct Vec {
-    float v[V];
-    __device__ float& operator[](int i) { return v[i]; }
-    __device__ const float& operator[](int i) const { return v[i]; }
+    T v[V];
+    __device__ T& operator[](int i) { return v[i]; }
+    __device__ const T& operator[](int i) const { return v[i]; }
 };
-template <int V>
-__device__ inline Vec<V> vzero() {
-    Vec<V> r;
+template <typename T, int V>
+__device__ inline Vec<T, V> vzero() {
+    Vec<T, V> r;
 #pragma unroll
-    for (int i = 0; i < V; ++i) r.v[i] = 0.f;
+    for (int i = 0; i < V; ++i) r.v[i] = T(0);
     return r;
 }
-template <int V>
-__device__ inline Vec<V> vload(const float* p) {
-    Vec<V> r;
-    if constexpr (V == 4) {
+template <typename T, int V>
+__device__ inline Vec<T, V> vload(const T* p) {
+    Vec<T, V> r;
+    if constexpr (V == 4 && sizeof(T) == 4) {
         const float4 t = *reinterpret_cast<const float4*>(p);
         r.v[0] = t.x; r.v[1] = t.y; r.v[2] = t.z; r.v[3] = t.w;
+    } else if constexpr (V == 4 && sizeof(T) == 8) {
+        const double2 a = reinterpret_cast<const double2*>(p)[0], b = reinterpret_cast<const double2*>(p)[1];
+        r.v[0] = a.x; r.v[1] = a.y; r.v[2] = b.x; r.v[3] = b.y;
     } else {
 #pragma unroll
         for (int i = 0; i < V; ++i) r.v[i] = p[i];
     }
     return r;
 }
-template <int V>
-__device__ inline void vstore(float* p, const Vec<V>& r) {
-    if constexpr (V == 4) {
+template <typename T, int V>
+__device__ inline void vstore(T* p, const Vec<T, V>& r) {
+    if constexpr (V == 4 && sizeof(T) == 4) {
         *reinterpret_cast<float4*>(p) = make_float4(r.v[0], r.v[1], r.v[2], r.v[3]);
+    } else if constexpr (V == 4 && sizeof(T) == 8) {
+        reinterpret_cast<double2*>(p)[0] = make_double2(r.v[0], r.v[1]);
+        reinterpret_cast<double2*>(p)[1] = make_double2(r.v[2], r.v[3]);
     } else {
 #pragma unroll
         for (int i = 0; i < V; ++i) p[i] = r.v[i];
     }
 }
 
+template <typename T>
 struct Tap {
     int64_t off[4];  // element offset of the 4 corners (channel 0 of this head), -1 if outside
-    float w[4];
-    float lh, lw, hh, hw;
+    T w[4];
+    T lh, lw, hh, hw;
 };
 
-__device__ inline bool make_tap(float loc_x, float loc_y, int H, int W, int64_t level_start, int row_stride, Tap& t) {
-    const float h_im = loc_y * H - 0.5f;
-    const float w_im = loc_x * W - 0.5f;
+template <typename T>
+__device__ inline bool make_tap(T loc_x, T loc_y, int H, int W, int64_t level_start, int row_stride, Tap<T>& t) {
+    const T h_im = loc_y * H - T(0.5);
+    const T w_im = loc_x * W - T(0.5);
     if (!(h_im > -1 && w_im > -1 && h_im < H && w_im < W)) return false;
-    const int h_low = (int)floorf(h_im), w_low = (int)floorf(w_im);
+    const int h_low = (int)floor(h_im), w_low = (int)floor(w_im);
     const int h_high = h_low + 1, w_high = w_low + 1;
     t.lh = h_im - h_low;
     t.lw = w_im - w_low;
@@ -76,11 +86,11 @@ __device__ inline bool make_tap(float loc_x, float loc_y, int H, int W, int64_t 
 }
 
 // one thread = (b, q, h, group of V channels); V = 4 when D % 4 == 0 (16-byte taps), else 1
-template <int V>
-__global__ void k_msda_fwd(const float* __restrict__ value, const int64_t* __restrict__ shapes,
-                           const int64_t* __restrict__ lstart, const float* __restrict__ loc,
-                           const float* __restrict__ attn, int B, int S, int H, int D, int L, int Lq, int P,
-                           float* __restrict__ out) {
+template <typename T, int V>
+__global__ void k_msda_fwd(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                           const int64_t* __restrict__ lstart, const T* __restrict__ loc,
+                           const T* __restrict__ attn, int B, int S, int H, int D, int L, int Lq, int P,
+                           T* __restrict__ out) {
     const int QD = D / V;
     const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t total = int64_t(B) * Lq * H * QD;
@@ -91,23 +101,23 @@ __global__ void k_msda_fwd(const float* __restrict__ value, const int64_t* __res
     const int64_t bq = bqh / H;
     const int b = int(bq / Lq);
     const int row_stride = H * D;
-    const float* vbase = value + int64_t(b) * S * row_stride + h * D + cq * V;
-    const float* lp = loc + bqh * (int64_t(L) * P * 2);
-    const float* ap = attn + bqh * (int64_t(L) * P);
-    Vec<V> acc = vzero<V>();
+    const T* vbase = value + int64_t(b) * S * row_stride + h * D + cq * V;
+    const T* lp = loc + bqh * (int64_t(L) * P * 2);
+    const T* ap = attn + bqh * (int64_t(L) * P);
+    Vec<T, V> acc = vzero<T, V>();
     for (int l = 0; l < L; ++l) {
         const int Hl = int(shapes[2 * l]), Wl = int(shapes[2 * l + 1]);
         const int64_t ls = lstart[l];
         for (int p = 0; p < P; ++p) {
-            const float lx = lp[(l * P + p) * 2], ly = lp[(l * P + p) * 2 + 1];
-            const float aw = ap[l * P + p];
-            Tap t;
-            if (!make_tap(lx, ly, Hl, Wl, ls, row_stride, t)) continue;
-            Vec<V> sv = vzero<V>();
+            const T lx = lp[(l * P + p) * 2], ly = lp[(l * P + p) * 2 + 1];
+            const T aw = ap[l * P + p];
+            Tap<T> t;
+            if (!make_tap<T>(lx, ly, Hl, Wl, ls, row_stride, t)) continue;
+            Vec<T, V> sv = vzero<T, V>();
 #pragma unroll
             for (int c = 0; c < 4; ++c)
                 if (t.off[c] >= 0) {
-                    const Vec<V> x = vload<V>(vbase + t.off[c]);
+                    const Vec<T, V> x = vload<T, V>(vbase + t.off[c]);
 #pragma unroll
                     for (int i = 0; i < V; ++i) sv[i] += t.w[c] * x[i];
                 }
@@ -115,15 +125,15 @@ __global__ void k_msda_fwd(const float* __restrict__ value, const int64_t* __res
             for (int i = 0; i < V; ++i) acc[i] += aw * sv[i];
         }
     }
-    vstore<V>(out + bqh * D + cq * V, acc);
+    vstore<T, V>(out + bqh * D + cq * V, acc);
 }
 
-template <int V, bool SHUFFLE>
-__global__ void k_msda_bwd(const float* __restrict__ value, const int64_t* __restrict__ shapes,
-                           const int64_t* __restrict__ lstart, const float* __restrict__ loc,
-                           const float* __restrict__ attn, const float* __restrict__ gout, int B, int S, int H, int D,
-                           int L, int Lq, int P, float* __restrict__ gvalue, float* __restrict__ gloc,
-                           float* __restrict__ gattn) {
+template <typename T, int V, bool SHUFFLE>
+__global__ void k_msda_bwd(const T* __restrict__ value, const int64_t* __restrict__ shapes,
+                           const int64_t* __restrict__ lstart, const T* __restrict__ loc,
+                           const T* __restrict__ attn, const T* __restrict__ gout, int B, int S, int H, int D,
+                           int L, int Lq, int P, T* __restrict__ gvalue, T* __restrict__ gloc,
+                           T* __restrict__ gattn) {
     const int QD = D / V;
     const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     const int64_t total = int64_t(B) * Lq * H * QD;
@@ -136,29 +146,29 @@ __global__ void k_msda_bwd(const float* __restrict__ value, const int64_t* __res
     const int b = int(bq / Lq);
     const int row_stride = H * D;
     const int64_t voff = int64_t(b) * S * row_stride + h * D + cq * V;
-    const float* lp = loc + bqh * (int64_t(L) * P * 2);
-    const float* ap = attn + bqh * (int64_t(L) * P);
-    Vec<V> go = vload<V>(gout + bqh * D + cq * V);
-    if (!live) go = vzero<V>();
+    const T* lp = loc + bqh * (int64_t(L) * P * 2);
+    const T* ap = attn + bqh * (int64_t(L) * P);
+    Vec<T, V> go = vload<T, V>(gout + bqh * D + cq * V);
+    if (!live) go = vzero<T, V>();
     for (int l = 0; l < L; ++l) {
         const int Hl = int(shapes[2 * l]), Wl = int(shapes[2 * l + 1]);
         const int64_t ls = lstart[l];
         for (int p = 0; p < P; ++p) {
-            const float lx = lp[(l * P + p) * 2], ly = lp[(l * P + p) * 2 + 1];
-            const float aw = ap[l * P + p];
-            Tap t;
-            const bool inside = make_tap(lx, ly, Hl, Wl, ls, row_stride, t);  // uniform within a lane group
-            float g_attn = 0.f, g_x = 0.f, g_y = 0.f;
+            const T lx = lp[(l * P + p) * 2], ly = lp[(l * P + p) * 2 + 1];
+            const T aw = ap[l * P + p];
+            Tap<T> t;
+            const bool inside = make_tap<T>(lx, ly, Hl, Wl, ls, row_stride, t);  // uniform within a lane group
+            T g_attn = 0, g_x = 0, g_y = 0;
             if (inside) {
-                Vec<V> v[4];
+                Vec<T, V> v[4];
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
-                    v[c] = vzero<V>();
+                    v[c] = vzero<T, V>();
                     if (t.off[c] >= 0) {
-                        v[c] = vload<V>(value + voff + t.off[c]);
+                        v[c] = vload<T, V>(value + voff + t.off[c]);
                         if (live) {
-                            float* dst = gvalue + voff + t.off[c];
-                            const float wa = t.w[c] * aw;
+                            T* dst = gvalue + voff + t.off[c];
+                            const T wa = t.w[c] * aw;
 #pragma unroll
                             for (int i = 0; i < V; ++i) atomicAdd(dst + i, wa * go[i]);
                         }
@@ -166,10 +176,10 @@ __global__ void k_msda_bwd(const float* __restrict__ value, const int64_t* __res
                 }
 #pragma unroll
                 for (int i = 0; i < V; ++i) {
-                    const float sampled = t.w[0] * v[0][i] + t.w[1] * v[1][i] + t.w[2] * v[2][i] + t.w[3] * v[3][i];
-                    const float gh = -t.hw * v[0][i] - t.lw * v[1][i] + t.hw * v[2][i] + t.lw * v[3][i];
-                    const float gw = -t.hh * v[0][i] + t.hh * v[1][i] - t.lh * v[2][i] + t.lh * v[3][i];
-                    const float top = aw * go[i];
+                    const T sampled = t.w[0] * v[0][i] + t.w[1] * v[1][i] + t.w[2] * v[2][i] + t.w[3] * v[3][i];
+                    const T gh = -t.hw * v[0][i] - t.lw * v[1][i] + t.hw * v[2][i] + t.lw * v[3][i];
+                    const T gw = -t.hh * v[0][i] + t.hh * v[1][i] - t.lh * v[2][i] + t.lh * v[3][i];
+                    const T top = aw * go[i];
                     g_attn += go[i] * sampled;
                     g_x += gw * top;
                     g_y += gh * top;
@@ -207,9 +217,9 @@ static int check_msda(int B, int S, int H, int D, int L, int Lq, int P) {
 
 using namespace xm3d;
 
-extern "C" int xm3d_msda_forward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
-                                 const float* loc, const float* attn, int32_t B, int32_t S, int32_t H, int32_t D,
-                                 int32_t L, int32_t Lq, int32_t P, float* out, void* stream) {
+template <typename T>
+static int msda_forward_t(const T* value, const int64_t* spatial_shapes, const int64_t* level_start, const T* loc, const T* attn,
+                          int32_t B, int32_t S, int32_t H, int32_t D, int32_t L, int32_t Lq, int32_t P, T* out, void* stream) {
     int rc = check_msda(B, S, H, D, L, Lq, P);
     if (rc) return rc;
     if (int64_t(B) * Lq == 0) return XM3D_OK;
@@ -217,19 +227,19 @@ extern "C" int xm3d_msda_forward(const float* value, const int64_t* spatial_shap
     const bool vec4 = (D % 4 == 0) && ((reinterpret_cast<uintptr_t>(value) | reinterpret_cast<uintptr_t>(out)) & 15) == 0;
     const int64_t total = int64_t(B) * Lq * H * (vec4 ? D / 4 : D);
     if (vec4)
-        hipLaunchKernelGGL(k_msda_fwd<4>, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), value, spatial_shapes,
+        hipLaunchKernelGGL((k_msda_fwd<T, 4>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), value, spatial_shapes,
                            level_start, loc, attn, B, S, H, D, L, Lq, P, out);
     else
-        hipLaunchKernelGGL(k_msda_fwd<1>, dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), value, spatial_shapes,
+        hipLaunchKernelGGL((k_msda_fwd<T, 1>), dim3((total + 255) / 256), dim3(256), 0, as_stream(stream), value, spatial_shapes,
                            level_start, loc, attn, B, S, H, D, L, Lq, P, out);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
 
-extern "C" int xm3d_msda_backward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
-                                  const float* loc, const float* attn, const float* grad_out, int32_t B, int32_t S,
-                                  int32_t H, int32_t D, int32_t L, int32_t Lq, int32_t P, float* grad_value,
-                                  float* grad_loc, float* grad_attn, void* stream) {
+template <typename T>
+static int msda_backward_t(const T* value, const int64_t* spatial_shapes, const int64_t* level_start, const T* loc, const T* attn,
+                           const T* grad_out, int32_t B, int32_t S, int32_t H, int32_t D, int32_t L, int32_t Lq, int32_t P,
+                           T* grad_value, T* grad_loc, T* grad_attn, void* stream) {
     int rc = check_msda(B, S, H, D, L, Lq, P);
     if (rc) return rc;
     if (int64_t(B) * Lq == 0) return XM3D_OK;
@@ -241,8 +251,8 @@ extern "C" int xm3d_msda_backward(const float* value, const int64_t* spatial_sha
     const int64_t total = int64_t(B) * Lq * H * QD;
     const bool pow2 = (QD & (QD - 1)) == 0 && QD <= 64;
     dim3 grid((total + 255) / 256), blk(256);
-#define XM3D_BWD(V, SH)                                                                                              \
-    hipLaunchKernelGGL((k_msda_bwd<V, SH>), grid, blk, 0, as_stream(stream), value, spatial_shapes, level_start, loc, \
+#define XM3D_BWD(V, SH)                                                                                                 \
+    hipLaunchKernelGGL((k_msda_bwd<T, V, SH>), grid, blk, 0, as_stream(stream), value, spatial_shapes, level_start, loc, \
                        attn, grad_out, B, S, H, D, L, Lq, P, grad_value, grad_loc, grad_attn)
     if (vec4 && pow2) XM3D_BWD(4, true);
     else if (vec4) XM3D_BWD(4, false);
@@ -251,4 +261,32 @@ extern "C" int xm3d_msda_backward(const float* value, const int64_t* spatial_sha
 #undef XM3D_BWD
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
+}
+
+extern "C" int xm3d_msda_forward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                                 const float* loc, const float* attn, int32_t B, int32_t S, int32_t H, int32_t D,
+                                 int32_t L, int32_t Lq, int32_t P, float* out, void* stream) {
+    return msda_forward_t<float>(value, spatial_shapes, level_start, loc, attn, B, S, H, D, L, Lq, P, out, stream);
+}
+
+extern "C" int xm3d_msda_backward(const float* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                                  const float* loc, const float* attn, const float* grad_out, int32_t B, int32_t S,
+                                  int32_t H, int32_t D, int32_t L, int32_t Lq, int32_t P, float* grad_value,
+                                  float* grad_loc, float* grad_attn, void* stream) {
+    return msda_backward_t<float>(value, spatial_shapes, level_start, loc, attn, grad_out, B, S, H, D, L, Lq, P, grad_value, grad_loc,
+                                  grad_attn, stream);
+}
+
+extern "C" int xm3d_msda_forward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                                     const double* loc, const double* attn, int32_t B, int32_t S, int32_t H, int32_t D,
+                                     int32_t L, int32_t Lq, int32_t P, double* out, void* stream) {
+    return msda_forward_t<double>(value, spatial_shapes, level_start, loc, attn, B, S, H, D, L, Lq, P, out, stream);
+}
+
+extern "C" int xm3d_msda_backward_f64(const double* value, const int64_t* spatial_shapes, const int64_t* level_start,
+                                      const double* loc, const double* attn, const double* grad_out, int32_t B, int32_t S,
+                                      int32_t H, int32_t D, int32_t L, int32_t Lq, int32_t P, double* grad_value,
+                                      double* grad_loc, double* grad_attn, void* stream) {
+    return msda_backward_t<double>(value, spatial_shapes, level_start, loc, attn, grad_out, B, S, H, D, L, Lq, P, grad_value,
+                                   grad_loc, grad_attn, stream);
 }

@@ -78,7 +78,9 @@ __global__ void k_nearest_unpack(const unsigned long long* __restrict__ best64, 
                                  int64_t* __restrict__ out) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (counts && counts[0] < n) n = counts[0];
-    if (i < n) out[i] = int64_t(best64[i] & 0xFFFFFFFFull);
+    // no live reference point (counts[1] == 0): every slice returned early and best64 still holds its 0xFF fill ->
+    // index 0, like the unsplit path (never an out-of-range index for the caller's gather)
+    if (i < n) out[i] = (best64[i] == ~0ull) ? 0 : int64_t(best64[i] & 0xFFFFFFFFull);
 }
 
 // Segmented form for the per-view hole filling of a whole scene batch in one launch: `pts` holds, for every segment

@@ -1,8 +1,9 @@
 """Train / infer drivers: the counterparts of /root/reference/run/train.py (main_worker :126-393, train_net :403-878)
 and run/infer.py (validate :338-911) on synthetic ScanNet-shaped scenes (no dataset offline).
 
-Kept from the reference: one process per GPU, ``dist_backend`` from the yaml ("nccl" == RCCL on ROCm), DDP with
-``find_unused_parameters=True``, MinkowskiSyncBatchNorm when the per-GPU batch is < 4 (train.py:185-187), AdamW with the two
+Kept from the reference: one process per GPU, ``dist_backend`` from the yaml ("nccl" == RCCL on ROCm), DDP (without the
+reference's ``find_unused_parameters=True``: every trainable parameter takes part in every iteration here, so the extra
+autograd-graph traversal per iteration buys nothing), MinkowskiSyncBatchNorm when the per-GPU batch is < 4 (train.py:185-187), AdamW with the two
 parameter groups of train.py:152-169 (3D nets at lr_3d, everything trainable else at lr_others, frozen SD/CLIP skipped),
 cosine / poly LR per iteration (train.py:575-586), checkpoint ``model/model_last.pth.tar`` every epoch (train.py:354-390),
 metrics all-reduced as SUMs (train.py:640-652, infer.py:717-726).
@@ -50,6 +51,20 @@ def build_optimizer(model, cfg):
     return torch.optim.AdamW([{"params": g3d, "lr": cfg.lr_3d}, {"params": rest, "lr": cfg.lr_others}], fused=fused)
 
 
+def set_contra_schedule(core, cfg, epoch):
+    """run/train.py:292-307: the mask-level 3D contrastive loss is switched off (weight 0, not even computed) before
+    ``cfg.start_contra`` and enters the objective with ``cfg.loss_weight.loss_3d_contra`` from that epoch on."""
+    if not bool(getattr(cfg, "mask_contra_3d", False)):
+        return
+    crit = core.criterion
+    if epoch < int(getattr(cfg, "start_contra", 0)):
+        crit.weight_dict["loss_3d_contra"] = 0
+        crit.mask_contra_3d = False
+    else:
+        crit.weight_dict["loss_3d_contra"] = cfg.loss_weight["loss_3d_contra"]
+        crit.mask_contra_3d = True
+
+
 def synthetic_labels(scene, n_classes=19, seed=0):
     """deterministic per-point ground truth for the synthetic room: class by height band x quadrant"""
     p = scene.points
@@ -70,7 +85,7 @@ def train(cfg, epochs=1, iters_per_epoch=4, views_per_gpu=2, save_path=None, res
         if views_per_gpu < 4:
             ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)
             torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)
-        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=True)
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[dev.index], find_unused_parameters=False)
     opt = build_optimizer(model, cfg)
     start_epoch, best = 0, 0.0
     if resume:
@@ -83,6 +98,7 @@ def train(cfg, epochs=1, iters_per_epoch=4, views_per_gpu=2, save_path=None, res
     K = cfg.classes
     for epoch in range(start_epoch, epochs):
         model.train()
+        set_contra_schedule(core, cfg, epoch)
         meter = metrics.AverageMeter()
         t0 = time.perf_counter()
         for i in range(iters_per_epoch):

@@ -49,20 +49,12 @@ def _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, 
 
 def ms_deform_attn_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step):
     _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step)
-    if value.dtype == torch.float64:
-        # the device kernels are f32 (the pixel decoder forces .float(), msdeformattn.py:320,344); f64 callers get
-        # the f32 kernel result upcast - documented precision limit, not a different code path
-        out = ops.msda_forward(value.float(), spatial_shapes, level_start_index, sampling_loc.float(), attn_weight.float())
-        return out.double()
+    # float and double both have device kernels (the reference dispatches over both, ms_deform_attn_cuda.cu:64)
     return ops.msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight)
 
 
 def ms_deform_attn_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output, im2col_step):
     _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step, (("grad_output", grad_output),))
-    if value.dtype == torch.float64:
-        gs = ops.msda_backward(value.float(), spatial_shapes, level_start_index, sampling_loc.float(), attn_weight.float(),
-                               grad_output.float().contiguous())
-        return [g.double() for g in gs]
     return list(ops.msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output))
 
 

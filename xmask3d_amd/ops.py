@@ -413,35 +413,44 @@ def geglu(x):
 
 
 # ---------------------------------------------------------------- deformable attention
+def _msda_dtype(value):
+    if value.dtype not in (torch.float32, torch.float64):
+        raise TypeError(f"msda: float32 or float64 tensors required, got {value.dtype}")
+    return value.dtype, ("" if value.dtype == torch.float32 else "_f64")
+
+
 def msda_forward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight):
-    _req(value, torch.float32, "value", 4)
+    dt, sfx = _msda_dtype(value)
+    _req(value, dt, "value", 4)
     _req(spatial_shapes, torch.int64, "spatial_shapes", 2)
     _req(level_start_index, torch.int64, "level_start_index", 1)
-    _req(sampling_loc, torch.float32, "sampling_loc", 6)
-    _req(attn_weight, torch.float32, "attn_weight", 5)
+    _req(sampling_loc, dt, "sampling_loc", 6)
+    _req(attn_weight, dt, "attn_weight", 5)
     B, S, H, D = value.shape
     _, Lq, _, L, P, _ = sampling_loc.shape
-    out = torch.empty((B, Lq, H * D), dtype=torch.float32, device=value.device)
-    check(lib().xm3d_msda_forward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(sampling_loc),
-                                  _ptr(attn_weight), B, S, H, D, L, Lq, P, _ptr(out), _stream()), "xm3d_msda_forward")
+    out = torch.empty((B, Lq, H * D), dtype=dt, device=value.device)
+    check(getattr(lib(), "xm3d_msda_forward" + sfx)(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(sampling_loc),
+                                                     _ptr(attn_weight), B, S, H, D, L, Lq, P, _ptr(out), _stream()),
+          "xm3d_msda_forward" + sfx)
     return out
 
 
 def msda_backward(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, grad_output):
-    _req(value, torch.float32, "value", 4)
+    dt, sfx = _msda_dtype(value)
+    _req(value, dt, "value", 4)
     _req(spatial_shapes, torch.int64, "spatial_shapes", 2)
     _req(level_start_index, torch.int64, "level_start_index", 1)
-    _req(sampling_loc, torch.float32, "sampling_loc", 6)
-    _req(attn_weight, torch.float32, "attn_weight", 5)
-    _req(grad_output, torch.float32, "grad_output")
+    _req(sampling_loc, dt, "sampling_loc", 6)
+    _req(attn_weight, dt, "attn_weight", 5)
+    _req(grad_output, dt, "grad_output")
     B, S, H, D = value.shape
     _, Lq, _, L, P, _ = sampling_loc.shape
     gv = torch.zeros_like(value)
     gl = torch.zeros_like(sampling_loc)
     ga = torch.zeros_like(attn_weight)
-    check(lib().xm3d_msda_backward(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(sampling_loc),
-                                   _ptr(attn_weight), _ptr(grad_output), B, S, H, D, L, Lq, P, _ptr(gv), _ptr(gl), _ptr(ga),
-                                   _stream()), "xm3d_msda_backward")
+    check(getattr(lib(), "xm3d_msda_backward" + sfx)(_ptr(value), _ptr(spatial_shapes), _ptr(level_start_index), _ptr(sampling_loc),
+                                                      _ptr(attn_weight), _ptr(grad_output), B, S, H, D, L, Lq, P, _ptr(gv), _ptr(gl),
+                                                      _ptr(ga), _stream()), "xm3d_msda_backward" + sfx)
     return gv, gl, ga
 
 

@@ -162,9 +162,9 @@ def nearest_valid_fill(xyz: torch.Tensor, valid: torch.Tensor):
     counts = torch.stack([n - n_valid, n_valid]).to(torch.int64)
     nn = ops.nearest_index(xyz[q_order].contiguous(), xyz[r_order].contiguous(), None, counts)
     fill = torch.arange(n, device=xyz.device)
-    live = torch.arange(n, device=xyz.device) < (n - n_valid)
+    live = (torch.arange(n, device=xyz.device) < (n - n_valid)) & (n_valid > 0)  # nothing valid anywhere: identity
     # scatter the answers of the live queries back; every other point keeps its own index
-    return fill.scatter(0, q_order, torch.where(live, r_order[nn], q_order))
+    return fill.scatter(0, q_order, torch.where(live, r_order[nn.clamp_(0, n - 1)], q_order))
 
 
 def nearest_valid_fill_segmented(xyz, valid, seg, n_seg, max_seg_points):
