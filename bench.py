@@ -221,15 +221,8 @@ def main():
     torch.set_num_threads(host_threads())
     log(f"building model (seeded random weights), host threads {host_threads()}")
     cpu_model = XMASK3d(cfg, prune_dead_compute=not args.faithful_dead_compute).eval()
-    model = copy.deepcopy(cpu_model).to(dev).eval()
     dense_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
-    model.set_dense_dtype(dense_dtype)
-    if not args.nchw:
-        model.set_channels_last(True)
-    if dense_dtype == torch.bfloat16:
-        model.cast_head_weights()
-    if not args.no_graph:
-        model.enable_dense_graph()
+    model = pipeline.make_inference_model(cpu_model, dev, dense_dtype, channels_last=not args.nchw, graphs=not args.no_graph)
 
     scene = synthetic.scene_s1()
     sd = pipeline.SceneOnDevice(scene, dev)

@@ -122,6 +122,18 @@ int xm3d_spconv_fwd_tiles(const float* in, int64_t n_in, int32_t cin, const floa
                           const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order,
                           int64_t n_out, const float* scale, const float* shift, const float* residual,
                           int32_t relu, float* out, int32_t ksplit, float* slab, void* stream);
+/* Split-operand form (algo 4, the default on the MinkUNets): same tiled rulebook, same result contract and epilogue as
+ * xm3d_spconv_fwd_tiles, computed on the bf16 matrix cores with every f32 operand split into two bf16 terms (three
+ * products per f32 product, f32 accumulation: error <= ~2^-16 per term, inside the 2e-5 per-conv bound of the f32 kernel;
+ * summation order fixed -> bitwise reproducible).  Wq = xm3d_spconv_pack_weight_split(W): K*cin*cout*4 bytes (bf16 hi and
+ * lo parts in MFMA-fragment order).  Cin, Cout multiples of 32.  xm3d_spconv_split_channels(cout) = output channels one
+ * workgroup owns (96 / 64 / 32): callers size the split-K factor from the resulting workgroup count. */
+int xm3d_spconv_pack_weight_split(const float* W, int32_t K, int32_t cin, int32_t cout, void* Wq, void* stream);
+int xm3d_spconv_split_channels(int32_t cout);
+int xm3d_spconv_fwd_split(const float* in, int64_t n_in, int32_t cin, const void* Wq, int32_t K, int32_t cout,
+                          const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order,
+                          int64_t n_out, const float* scale, const float* shift, const float* residual,
+                          int32_t relu, float* out, int32_t ksplit, float* slab, void* stream);
 /* Pre-pack W (K,Cin,Cout) into the MFMA B-fragment layout used by algo 2 (same byte size). */
 int xm3d_spconv_pack_weight(const float* W, int32_t K, int32_t cin, int32_t cout, float* Wp, void* stream);
 /* dgrad: gin[i,:] = sum over (k,o) with nbr[k,o]==i of gout[o,:] @ W[k]^T, computed as a

@@ -38,17 +38,70 @@ def test_conv_kernels_match_oracle(dev, cin, cout, ks, n):
     scale, shift, res = torch.rand(cout) + 0.5, torch.randn(cout), torch.randn(N, cout)
     ref_plain = so.spconv(f.double(), W.double(), nbr.cpu().numpy()).float()
     ref_epi = torch.relu(ref_plain * scale + shift + res)
-    algos = [ops.ALGO_SCALAR] + ([ops.ALGO_MFMA, ops.ALGO_TILES] if ops.mfma_eligible(cin, cout) else [])
+    algos = [ops.ALGO_SCALAR] + ([ops.ALGO_MFMA, ops.ALGO_TILES, ops.ALGO_SPLIT] if ops.mfma_eligible(cin, cout) else [])
     for algo in algos:
         for order in (None, cm.order(1)):
-            if algo == ops.ALGO_TILES and order is None:
+            if algo in (ops.ALGO_TILES, ops.ALGO_SPLIT) and order is None:
                 continue  # the tiled rulebook is built for the manager's processing order
-            tiles = cm.tiles(1, 1, ks) if algo == ops.ALGO_TILES else None
+            tiles = cm.tiles(1, 1, ks) if algo in (ops.ALGO_TILES, ops.ALGO_SPLIT) else None
             out = ops.spconv_fwd(f.to(dev), W.to(dev), nbr, N, order=order, algo=algo, tiles=tiles)
             assert _rel(out.cpu(), ref_plain) < 2e-5, (algo, order is None)
             out = ops.spconv_fwd(f.to(dev), W.to(dev), nbr, N, order=order, scale=scale.to(dev), shift=shift.to(dev),
                                  residual=res.to(dev), relu=True, algo=algo, tiles=tiles)
             assert _rel(out.cpu(), ref_epi) < 2e-5, (algo, order is None)
+
+
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 32), (32, 64), (64, 64), (96, 96), (128, 96), (96, 256), (192, 128),
+                                      (256, 256), (384, 256), (128, 192), (96, 128), (64, 96), (32, 96), (96, 32), (96, 64)])
+def test_split_kernel_every_instantiation(dev, cin, cout):
+    """algo 4 (bf16 split-operand kernel): every (output-channel tile, channel chunk) instantiation, ragged tiles, k = 3 / 2 / 1,
+    with and without split-K, against the f64 oracle at the f32 kernel's own 2e-5 bound; bitwise reproducible."""
+    from xmask3d_amd import ops
+
+    torch.manual_seed(cin * 7 + cout)
+    c = _coords(2300, cin + cout, hi=20)
+    N = len(c)
+    cm = ops.CoordinateManager(torch.from_numpy(c).to(dev))
+    f = torch.randn(N, cin)
+    scale, shift, res = torch.rand(cout) + 0.5, torch.randn(cout), torch.randn(N, cout)
+    for ks in (3, 1):
+        nbr = None if ks == 1 else cm.kernel_map(1, 1, ks)
+        tiles = cm.tiles(1, 1, ks)
+        W = torch.randn(ks ** 3, cin, cout) / (cin * 4) ** 0.5
+        ident = torch.arange(N, dtype=torch.int32)[None].numpy()
+        ref = so.spconv(f.double(), W.double(), ident if nbr is None else nbr.cpu().numpy()).float()
+        ref_epi = torch.relu(ref * scale + shift + res)
+        for ksplit in (1, 3 if ks == 3 else 1):
+            out = ops.spconv_fwd(f.to(dev), W.to(dev), nbr, N, order=cm.order(1), algo=ops.ALGO_SPLIT, tiles=tiles, ksplit=ksplit)
+            assert _rel(out.cpu(), ref) < 2e-5, (ks, ksplit, _rel(out.cpu(), ref))
+            out2 = ops.spconv_fwd(f.to(dev), W.to(dev), nbr, N, order=cm.order(1), scale=scale.to(dev), shift=shift.to(dev),
+                                  residual=res.to(dev), relu=True, algo=ops.ALGO_SPLIT, tiles=tiles, ksplit=ksplit)
+            assert _rel(out2.cpu(), ref_epi) < 2e-5
+            again = ops.spconv_fwd(f.to(dev), W.to(dev), nbr, N, order=cm.order(1), algo=ops.ALGO_SPLIT, tiles=tiles, ksplit=ksplit)
+            assert torch.equal(out, again)
+
+
+def test_roofline_shape_s1_full_96_to_96(dev):
+    """the layer bench.py's `roofline` object is measured on (S1-full, 107 k voxels, 96 -> 96, k = 3, 418 k pairs): both
+    tiled kernels against the oracle's per-offset gather-matmul-scatter in f64"""
+    from xmask3d_amd import ops, synthetic
+
+    sc = synthetic.scene_s1()
+    grid, inds, inv = ops.voxelize(torch.from_numpy(sc.points).to(dev), np.diag([50.0, 50.0, 50.0, 1.0]))
+    coords = torch.cat([torch.zeros(grid.shape[0], 1, dtype=torch.int32, device=dev), grid], 1).contiguous()
+    cm = ops.CoordinateManager(coords)
+    n = coords.shape[0]
+    nbr, tiles, order = cm.kernel_map(1, 1, 3), cm.tiles(1, 1, 3), cm.order(1)
+    assert n > 100000 and int((nbr >= 0).sum()) > 400000
+    assert (nbr.cpu().numpy() == so.kernel_map(coords.cpu().numpy(), coords.cpu().numpy(), 3, 1)).all()
+    g = torch.Generator().manual_seed(1)
+    feats, W = torch.randn(n, 96, generator=g), torch.randn(27, 96, 96, generator=g) * 0.05
+    ref = torch.relu(so.spconv(feats.double(), W.double(), nbr.cpu().numpy())).float()
+    for algo in (ops.ALGO_TILES, ops.ALGO_SPLIT):
+        out = ops.spconv_fwd(feats.to(dev), W.to(dev), nbr, n, order=order, tiles=tiles, relu=True, algo=algo)
+        err = _rel(out.cpu(), ref)
+        print(f"[S1-full 96->96 algo {algo}] rel err {err:.3e}")
+        assert err < 2e-5, (algo, err)
 
 
 def test_split_k_is_deterministic_and_matches(dev):

@@ -84,4 +84,8 @@ int sort_pairs_u64(const uint64_t* kin, uint64_t* kout, const int32_t* vin, int3
 size_t scan_ws_bytes(int64_t n);
 int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, size_t ws_bytes, hipStream_t s);
 
+// out = epi(sum_z slab[z]) in fixed z order (spconv.hip; shared by the split-K paths of both sparse-conv kernels)
+int launch_slab_reduce(const float* slab, int ksplit, int64_t n_out, int cout, const float* scale, const float* shift,
+                       const float* residual, int relu, float* out, hipStream_t s);
+
 }  // namespace xm3d

@@ -429,6 +429,16 @@ __global__ void k_slab_reduce(const float* __restrict__ slab, int ksplit, int64_
     }
 }
 
+// host-side launcher shared with spconv_split.hip
+int launch_slab_reduce(const float* slab, int ksplit, int64_t n_out, int cout, const float* scale, const float* shift,
+                       const float* residual, int relu, float* out, hipStream_t s) {
+    const int64_t n4 = n_out * cout / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out);
+    return 0;
+}
+
 // ------------------------------------------------------------------ weight gradient
 // gW[k][ci][co] = sum_o in[nbr[k,o]][ci] * gout[o][co].
 // grid = (row chunks, (cin/32)*(cout/32) tiles, K); each wave owns one 32x32 tile of gW[k] and a slice of

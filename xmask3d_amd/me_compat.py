@@ -272,9 +272,11 @@ class _ConvBase(nn.Module):
     def _packed_weight(self, k3):
         if not ops.mfma_eligible(self.in_channels, self.out_channels):
             return None
-        key = (k3.data_ptr(), self.kernel._version, k3.device)
+        algo = ops.default_tiled_algo(self.in_channels, self.out_channels, self.kernel_volume)
+        key = (k3.data_ptr(), self.kernel._version, k3.device, algo)
         if self._packed_key != key:
-            self._packed = ops.pack_weight(k3.detach().contiguous())
+            pack = ops.pack_weight_split if algo == ops.ALGO_SPLIT else ops.pack_weight
+            self._packed = pack(k3.detach().contiguous())
             self._packed_key = key
         return self._packed
 

@@ -194,7 +194,20 @@ class CoordinateManager:
 
 
 # ---------------------------------------------------------------- sparse conv
-ALGO_AUTO, ALGO_SCALAR, ALGO_MFMA, ALGO_TILES = 0, 1, 2, 3
+ALGO_AUTO, ALGO_SCALAR, ALGO_MFMA, ALGO_TILES, ALGO_SPLIT = 0, 1, 2, 3, 4
+
+
+def default_tiled_algo(cin=None, cout=None, K=None):
+    """algo for MFMA-eligible layers that have a tiled rulebook: the split-operand bf16 kernel (algo 4) unless
+    XM3D_SPCONV_ALGO=tiles selects the exact-f32 MFMA kernel (algo 3).  The 32 -> 32 k=3 layers stay on algo 3: with two
+    16-channel tiles per row tile the producers' gather + split work is not amortised (61 vs 50 us at tensor stride 2)."""
+    import os
+
+    if os.environ.get("XM3D_SPCONV_ALGO", "split") == "tiles":
+        return ALGO_TILES
+    if cin == 32 and cout == 32 and K is not None and K > 8:
+        return ALGO_TILES
+    return ALGO_SPLIT
 
 
 def pack_weight(kernel: torch.Tensor) -> torch.Tensor:
@@ -203,6 +216,15 @@ def pack_weight(kernel: torch.Tensor) -> torch.Tensor:
     out = torch.empty_like(kernel)
     K, cin, cout = kernel.shape
     check(lib().xm3d_spconv_pack_weight(_ptr(kernel), K, cin, cout, _ptr(out), _stream()), "xm3d_spconv_pack_weight")
+    return out
+
+
+def pack_weight_split(kernel: torch.Tensor) -> torch.Tensor:
+    """(K,Cin,Cout) f32 -> bf16 hi/lo fragments for xm3d_spconv_fwd_split (same byte size; opaque f32-typed buffer)."""
+    _req(kernel, torch.float32, "kernel", 3)
+    out = torch.empty_like(kernel)
+    K, cin, cout = kernel.shape
+    check(lib().xm3d_spconv_pack_weight_split(_ptr(kernel), K, cin, cout, _ptr(out), _stream()), "xm3d_spconv_pack_weight_split")
     return out
 
 
@@ -234,22 +256,28 @@ def spconv_fwd(feats, kernel, nbr, n_out, order=None, scale=None, shift=None, re
         _req(order, torch.int32, "order", 1)
         assert order.numel() == n_out
     if algo == ALGO_AUTO:
-        algo = (ALGO_TILES if tiles is not None else ALGO_MFMA) if mfma_eligible(cin, cout) else ALGO_SCALAR
+        algo = (default_tiled_algo(cin, cout, K) if tiles is not None else ALGO_MFMA) if mfma_eligible(cin, cout) else ALGO_SCALAR
     w = kernel
     if algo in (ALGO_MFMA, ALGO_TILES):
         w = packed if packed is not None else pack_weight(kernel)
+    elif algo == ALGO_SPLIT:
+        w = packed if packed is not None else pack_weight_split(kernel)
     out = torch.empty((n_out, cout), dtype=torch.float32, device=feats.device)
-    if algo == ALGO_TILES:
+    if algo in (ALGO_TILES, ALGO_SPLIT):
         if tiles is None:
-            raise RuntimeError("ALGO_TILES needs the tiled rulebook (CoordinateManager.tiles)")
+            raise RuntimeError("ALGO_TILES / ALGO_SPLIT need the tiled rulebook (CoordinateManager.tiles)")
         tsrc, tdst, tcnt = tiles
+        split = algo == ALGO_SPLIT
         if ksplit is None:
-            wgs = ((n_out + 255) // 256) * (cout // lib().xm3d_spconv_tile_channels(cin, cout))
-            ksplit = 1 if wgs >= 256 else max(1, min(K, 768 // max(wgs, 1)))
+            ctt = lib().xm3d_spconv_split_channels(cout) if split else lib().xm3d_spconv_tile_channels(cin, cout)
+            wgs = ((n_out + 255) // 256) * (cout // ctt)
+            full = 128 if split else 256  # the split kernel runs one 512-thread workgroup per CU
+            ksplit = 1 if wgs >= full else max(1, min(K, (384 if split else 768) // max(wgs, 1)))
         slab = torch.empty((ksplit, n_out, cout), dtype=torch.float32, device=feats.device) if ksplit > 1 else None
-        check(lib().xm3d_spconv_fwd_tiles(_ptr(feats), feats.shape[0], cin, _ptr(w), K, cout, _ptr(tsrc), _ptr(tdst), _ptr(tcnt),
-                                          _ptr(order), n_out, _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)),
-                                          _ptr(out), ksplit, _ptr(slab), _stream()), "xm3d_spconv_fwd_tiles")
+        fn = lib().xm3d_spconv_fwd_split if split else lib().xm3d_spconv_fwd_tiles
+        check(fn(_ptr(feats), feats.shape[0], cin, _ptr(w), K, cout, _ptr(tsrc), _ptr(tdst), _ptr(tcnt),
+                 _ptr(order), n_out, _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)),
+                 _ptr(out), ksplit, _ptr(slab), _stream()), "xm3d_spconv_fwd_split" if split else "xm3d_spconv_fwd_tiles")
         return out
     check(lib().xm3d_spconv_fwd(_ptr(feats), feats.shape[0], cin, _ptr(w), K, cout, _ptr(nbr), _ptr(order), n_out,
                                 _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out), algo, _stream()),

@@ -31,6 +31,23 @@ def default_voxelizer(voxel_size=0.02, device="cuda"):
                      translation_augmentation_ratio_bound=((-0.2, 0.2), (-0.2, 0.2), (0, 0)), device=device)
 
 
+def make_inference_model(cpu_model, device, dense_dtype=torch.bfloat16, channels_last=True, graphs=True):
+    """The inference configuration bench.py measures (and tests/test_gpu_bench_parity.py checks against the oracle): a copy of
+    `cpu_model` on `device` with the frozen SD / CLIP nets in `dense_dtype`, channels-last conv nets, bf16 copies of the
+    head GEMM weights when the dense dtype is bf16, and the dense branch replayed as HIP graphs."""
+    import copy
+
+    model = copy.deepcopy(cpu_model).to(device).eval()
+    model.set_dense_dtype(dense_dtype)
+    if channels_last:
+        model.set_channels_last(True)
+    if dense_dtype == torch.bfloat16:
+        model.cast_head_weights()
+    if graphs:
+        model.enable_dense_graph()
+    return model
+
+
 class SceneOnDevice:
     """A scene uploaded once: points (f64), colours, per-view visibility / pixel labels / images."""
 
