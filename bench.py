@@ -29,6 +29,8 @@ import torch
 
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
 BF16_MFMA_PEAK_TF = 2500.0  # dense bf16
+HBM_PEAK_GBPS = 8000.0      # HBM3E spec (6.3 TB/s measured copy)
+SPCONV_PMC_TRAFFIC_BYTES = None  # filled from profiles/r02_roofline_spconv_pmc.txt once collected
 DENSE_TFLOP_PER_VIEW_MIN = 2.83  # SURVEY.md §8d, dead compute pruned
 DENSE_TFLOP_PER_VIEW_REF = 4.79  # as the reference computes
 
@@ -61,8 +63,10 @@ def event_ms(fn, reps, stream=None):
 
 
 def spconv_roofline(dev):
-    """Roofline of the dominant hand-written kernel, k_spconv_tiles<6>, on the S1-full 96->96 k=3 layer at
-    tensor stride 1 (MinkUNet34C block8): algorithmic FLOP = 2*P*Cin*Cout, bytes = gather+scatter model."""
+    """Roofline of the dominant hand-written kernel, k_spconv_split (algo 4), on the S1-full 96->96 k=3 layer at tensor
+    stride 1 (MinkUNet34C block8): algorithmic FLOP = 2*P*Cin*Cout, bytes = gather+scatter model.  The
+    kernel computes every f32 product as three bf16 MFMAs, so `achieved` (algorithmic TFLOP/s) is priced against the F32
+    matrix peak (157.3 TF = what an exact-f32 kernel could reach at best); the executed bf16 rate is listed beside it."""
     from xmask3d_amd import ops, synthetic
 
     sc = synthetic.scene_s1()
@@ -77,18 +81,61 @@ def spconv_roofline(dev):
     g = torch.Generator(device="cpu").manual_seed(1)
     feats = torch.randn(n, cin, generator=g).to(dev)
     W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev)
-    packed = ops.pack_weight(W)
-    ms = event_ms(lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=packed, tiles=tiles, relu=True), 20)
+    p4, p3 = ops.pack_weight_split(W), ops.pack_weight(W)
+    ms = event_ms(lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=p4, tiles=tiles, relu=True, algo=ops.ALGO_SPLIT), 20)
+    ms3 = event_ms(lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=p3, tiles=tiles, relu=True, algo=ops.ALGO_TILES), 10)
     flop = 2.0 * pairs * cin * cout
     gs_bytes = pairs * (cin + cout) * 4 + pairs * 8 + 27 * cin * cout * 4
-    return {"kernel": "xm3d::k_spconv_tiles<6>", "bound": "mfma", "achieved": flop / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF,
-            "unit": "TFLOP/s", "frac": flop / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF,
-            # HBM-side bytes per launch from rocprofv3 PMC passes on `bench.py --roofline-only` (profiles/r01_roofline_spconv_pmc.txt):
-            # FETCH_SIZE 207164 KiB + WRITE_SIZE 40130 KiB; algorithmic gather+scatter model below for comparison
-            "traffic": 253.2e6, "algorithmic_bytes_gather_scatter": gs_bytes,
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"kernel": "xm3d::k_spconv_split<6,1,96,4,3,2>", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF,
+            "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
+            # HBM-side bytes per launch from rocprofv3 PMC passes on `bench.py --roofline-only` (profiles/r02_roofline_spconv_pmc.txt)
+            "traffic": SPCONV_PMC_TRAFFIC_BYTES, "algorithmic_bytes_gather_scatter": gs_bytes,
             "algorithmic_bytes_compulsory": (2 * n * cin + 27 * cin * cout) * 4 + 8 * pairs,
             "avg_launch_us": ms * 1e3, "pairs": pairs, "voxels": n, "cin": cin, "cout": cout,
-            "gather_scatter_GBps": gs_bytes / (ms * 1e-3) / 1e9}
+            "gather_scatter_GBps": gs_bytes / (ms * 1e-3) / 1e9,
+            "executed_bf16_TFLOPs": 3 * tf, "executed_frac_of_bf16_peak": 3 * tf / BF16_MFMA_PEAK_TF,
+            "exact_f32_kernel_us": ms3 * 1e3, "exact_f32_kernel_frac": flop / (ms3 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF}
+
+
+def kernel_rooflines(dev):
+    """`roofline_kernels`: the other hand-written kernels that show up in the timed window, each measured live (HIP events)
+    on the shape it runs at in the bench forward (20 views) against the roof that bounds it."""
+    from xmask3d_amd import ops
+
+    out = []
+    g = torch.Generator(device="cpu").manual_seed(3)
+    # deformable attention forward, pixel-decoder shape, 20 views: gather model 5376*8*12*4 taps x 128 B per view and layer
+    B, S, H, D, L, P = 20, 5376, 8, 32, 3, 4
+    shapes = torch.tensor([[16, 16], [32, 32], [64, 64]], device=dev)
+    lsi = torch.tensor([0, 256, 1280], device=dev)
+    value = torch.randn(B, S, H, D, generator=g).to(dev)
+    loc = torch.rand(B, S, H, L, P, 2, generator=g).to(dev)
+    w = torch.softmax(torch.randn(B, S, H, L * P, generator=g), -1).view(B, S, H, L, P).to(dev)
+    ms = event_ms(lambda: ops.msda_forward(value, shapes, lsi, loc, w), 10)
+    gathered = B * S * H * L * P * 4 * D * 4
+    comp = (value.numel() + loc.numel() + w.numel() + B * S * H * D) * 4
+    out.append({"kernel": "xm3d::k_msda_fwd<float,4>", "bound": "hbm", "achieved": gathered / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
+                "unit": "GB/s", "frac": gathered / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "avg_launch_us": ms * 1e3,
+                "algorithmic_bytes": gathered, "compulsory_bytes": comp,
+                "note": "bytes = bilinear taps gathered (value tensor is L2 resident: 5.5 MB per view); 20 views"})
+    # GroupNorm (statistics + apply), channels-last bf16, the VAE's 256^2 x 256-channel maps, 5 views: 3 passes over the tensor
+    x = torch.randn(5, 256, 256, 256, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    gw, gb = torch.ones(256, device=dev, dtype=torch.bfloat16), torch.zeros(256, device=dev, dtype=torch.bfloat16)
+    ms = event_ms(lambda: ops.group_norm(x, 32, gw, gb, 1e-6, True), 10)
+    nbytes = 3 * x.numel() * 2
+    out.append({"kernel": "xm3d::k_gn_stats_nhwc + k_gn_apply_nhwc <bf16>", "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9,
+                "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "avg_launch_us": ms * 1e3,
+                "algorithmic_bytes": nbytes, "note": "two reads + one write of a (5,256,256,256) bf16 map, both launches"})
+    # exact nearest neighbour fill: 120 k queries x 40 k references, VALU bound: 8 flop per (query, reference)
+    q = torch.rand(120000, 3, generator=g).to(dev)
+    r = torch.rand(40000, 3, generator=g).to(dev)
+    ms = event_ms(lambda: ops.nearest_index(q, r), 10)
+    fl = 8.0 * q.shape[0] * r.shape[0]
+    out.append({"kernel": "xm3d::k_nearest", "bound": "valu", "achieved": fl / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF,
+                "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "avg_launch_us": ms * 1e3,
+                "note": "brute force 120 k x 40 k, 3 sub + 3 fma + compare per pair; peak = f32 vector rate"})
+    return out
 
 
 def balanced_groups(n_scenes, per_forward):
@@ -99,7 +146,7 @@ def balanced_groups(n_scenes, per_forward):
     return [n_scenes // ng + (1 if i < n_scenes % ng else 0) for i in range(ng)]
 
 
-def train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log):
+def train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log, train_dtype="fp32"):
     """SURVEY 8d metric (ii): training iterations per second at one view per GPU (BASELINE config 3: global batch = one
     scene per GPU), forward + 37 weighted losses + backward + AdamW, gradients all-reduced by DDP when world > 1."""
     import torch.distributed as dist
@@ -107,7 +154,7 @@ def train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log):
     from xmask3d_amd.driver import build_optimizer
     from xmask3d_amd.xmask3d import XMASK3d
 
-    tdt = torch.bfloat16 if args.train_dtype == "bf16" else torch.float32
+    tdt = torch.bfloat16 if train_dtype == "bf16" else torch.float32
     torch.manual_seed(cfg.manual_seed)
     model = XMASK3d(cfg).to(dev).set_dense_dtype(tdt).train()
     model.backbone.feature_extractor.ldm_extractor.enable_train_graph()
@@ -148,7 +195,7 @@ def train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log):
         raise SystemExit("bench: training loss is not finite")
     log(f"training leg: {args.train_steps} iterations in {dt:.3f} s")
     return {"iters_per_s": args.train_steps / dt, "ms_per_iter": dt / args.train_steps * 1e3, "steps": args.train_steps,
-            "views_per_gpu": 1, "global_batch_views": world, "frozen_nets_dtype": args.train_dtype,
+            "views_per_gpu": 1, "global_batch_views": world, "frozen_nets_dtype": train_dtype,
             "scope": "forward + 37 weighted losses (CPU Hungarian matching like the reference) + backward + AdamW; frozen UNet "
                      "forward/backward replayed as HIP graphs; DDP gradient all-reduce + MinkowskiSyncBatchNorm when n_gpus > 1"}
 
@@ -164,9 +211,11 @@ def main():
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find through the shipped find-db)")
     ap.add_argument("--scenes-per-forward", type=int, default=4,
                     help="scenes whose views share one forward (views are independent until the vote); 1 = one scene per forward")
-    ap.add_argument("--train-steps", type=int, default=0,
-                    help="also time this many training iterations (1 view per GPU, DDP when --gpus > 1) and report them under \"train\"")
-    ap.add_argument("--train-dtype", default="fp32", choices=["fp32", "bf16"], help="dtype of the frozen nets in the training leg")
+    ap.add_argument("--train-steps", type=int, default=4,
+                    help="training iterations timed after the inference steps (1 view per GPU, DDP when --gpus > 1), reported under "
+                         "\"train\" (fp32 as the reference trains, plus a bf16-frozen-nets run); 0 = skip")
+    ap.add_argument("--fp32-steps", type=int, default=4, help="inference steps of the fp32 configuration reported under \"fp32\" (0 = skip)")
+    ap.add_argument("--scene-pool", type=int, default=4, help="distinct seeded scenes the timed loop cycles through")
     ap.add_argument("--nchw", action="store_true", help="keep NCHW activations in the frozen conv nets (default: channels-last)")
     ap.add_argument("--no-graph", action="store_true", help="launch the dense branch eagerly instead of replaying a HIP graph")
     ap.add_argument("--faithful-dead-compute", action="store_true", help="also run what the reference computes and discards")
@@ -224,39 +273,73 @@ def main():
     dense_dtype = torch.bfloat16 if args.dtype == "bf16" else torch.float32
     model = pipeline.make_inference_model(cpu_model, dev, dense_dtype, channels_last=not args.nchw, graphs=not args.no_graph)
 
-    scene = synthetic.scene_s1()
-    sd = pipeline.SceneOnDevice(scene, dev)
+    # distinct seeded scenes (same generator, different seeds: different geometry, point counts and images), resident in
+    # HBM before the timed region; the timed loop cycles through them
+    scenes = [synthetic.scene_s1(seed=cfg.manual_seed + 101 * i) for i in range(max(1, args.scene_pool))]
+    scene = scenes[0]
+    sds = [pipeline.SceneOnDevice(sc, dev) for sc in scenes]
+    sd = sds[0]
     voxelizer = pipeline.default_voxelizer(cfg.voxel_size, dev)
     np.random.seed(cfg.manual_seed + rank)
 
     G = 1 if (args.no_graph or args.views_per_batch) else max(1, args.scenes_per_forward)
 
-    def group_sizes(n_scenes):
-        return balanced_groups(n_scenes, G)
+    def group_sizes(n_scenes, g=None):
+        return balanced_groups(n_scenes, g or G)
 
-    def run(n_scenes):
-        """n_scenes steps (one step = one scene).  Scenes go through the model in groups of G (all views of the group in
+    def run(mdl, n_scenes, g=None):
+        """n_scenes steps (one step = one scene).  Scenes go through the model in groups of g (all views of the group in
         one forward); consecutive groups are software-pipelined (the next group's front is issued on side streams)."""
-        if G == 1 and (args.no_graph or args.views_per_batch):
+        g = g or G
+        if g == 1 and (args.no_graph or args.views_per_batch):
             for k in range(n_scenes):
-                out = pipeline.infer_scene(model, sd, cfg, voxelizer, views_per_batch=args.views_per_batch or None)
+                out = pipeline.infer_scene(mdl, sds[k % len(sds)], cfg, voxelizer, views_per_batch=args.views_per_batch or None)
             return out
-        sizes = group_sizes(n_scenes)
-        for gi, g in enumerate(sizes):
-            nxt = [sd] * sizes[gi + 1] if gi + 1 < len(sizes) else None
-            out = pipeline.infer_scenes(model, [sd] * g, cfg, voxelizer, next_scenes=nxt)[-1]
+        sizes = group_sizes(n_scenes, g)
+        groups, k = [], 0
+        for sz in sizes:
+            groups.append([sds[(k + j) % len(sds)] for j in range(sz)])
+            k += sz
+        for gi, grp in enumerate(groups):
+            nxt = groups[gi + 1] if gi + 1 < len(groups) else None
+            out = pipeline.infer_scenes(mdl, grp, cfg, voxelizer, next_scenes=nxt)[-1]
         return out
 
-    if not args.no_graph and not args.views_per_batch:
+    def capture(mdl, n_steps, g=None):
         # setup, not a step: capture the HIP graphs of every batch shape the timed region will meet
         with torch.no_grad():
-            for g in sorted(set(group_sizes(args.steps)) | set(group_sizes(1))):
-                model._graphs_for(torch.cat([sd.img_all] * g), torch.zeros(g * len(sd.views), 768, device=dev))
+            for gs in sorted(set(group_sizes(n_steps, g)) | set(group_sizes(1, g))):
+                mdl._graphs_for(torch.cat([sd.img_all] * gs), torch.zeros(gs * len(sd.views), 768, device=dev))
         torch.cuda.synchronize()
+
+    def timed(mdl, n_steps, g=None):
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        preds = run(mdl, n_steps, g)
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        ok = all(bool(torch.isfinite(p.float()).all()) and int(p.min()) >= 0 and int(p.max()) < cfg.test_classes for p in preds)
+        if not ok:
+            raise SystemExit("bench: scene predictions are not finite class ids - refusing to report a number")
+        if world > 1:
+            t = torch.tensor([dt], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t.item())
+        return dt
+
+    graphed = not args.no_graph and not args.views_per_batch
+    if graphed:
+        capture(model, args.steps)
+        capture(model, 1, 1)
         log(f"HIP graphs captured for {G} scene(s) per forward")
     log("model on device; warmup")
     for i in range(args.warmup):
-        run(1)
+        run(model, 1)
         torch.cuda.synchronize()
         log(f"warmup step {i} done")
     torch.cuda.synchronize()
@@ -267,29 +350,35 @@ def main():
 
     gc.collect()
     gc.freeze()
-    if world > 1:
-        dist.barrier()
     from xmask3d_amd import ops as _ops
 
     marker = torch.zeros(1, 3, dtype=torch.int32, device=dev)
     _ops.fnv_keys(marker)  # k_fnv_only: a dispatch that only ever marks the timed window in kernel traces (profiles/)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    preds = run(args.steps)
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+    elapsed = timed(model, args.steps)
     _ops.fnv_keys(marker)
-    ok = all(bool(torch.isfinite(p.float()).all()) and int(p.min()) >= 0 and int(p.max()) < cfg.test_classes for p in preds)
-    if not ok:
-        raise SystemExit("bench: scene predictions are not finite class ids - refusing to report a number")
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-    train = train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log) if args.train_steps > 0 else None
+    # latency of ONE scene (one scene per forward, nothing to pipeline against): reported beside the throughput number
+    latency_ms = None
+    if graphed and world == 1:
+        run(model, 1, 1)
+        latency_ms = timed(model, 3, 1) / 3 * 1e3
+    # the same pipeline with every net in fp32 (the reference's arithmetic; BASELINE config 2 names bf16, hence not `value`)
+    fp32 = None
+    if args.dtype == "bf16" and args.fp32_steps > 0 and graphed:
+        m32 = pipeline.make_inference_model(cpu_model, dev, torch.float32, channels_last=not args.nchw, graphs=True)
+        capture(m32, args.fp32_steps)
+        run(m32, 1)
+        dt32 = timed(m32, args.fp32_steps)
+        fp32 = {"value": world * args.fp32_steps / dt32, "unit": "scenes/s", "ms_per_step": dt32 / args.fp32_steps * 1e3, "steps": args.fp32_steps,
+                "dtype": "f32 everywhere (sparse 3D on the bf16x3 split-operand MFMA kernel, f32 accumulate)"}
+        del m32
+        torch.cuda.empty_cache()
+        log(f"fp32 configuration: {fp32['value']:.2f} scenes/s")
+    train = None
+    if args.train_steps > 0:
+        train = train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log, "fp32")
+        torch.cuda.empty_cache()
+        train["bf16_frozen_nets"] = train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log, "bf16")
+        torch.cuda.empty_cache()
     if rank != 0:
         if world > 1:
             dist.destroy_process_group()
@@ -314,7 +403,7 @@ def main():
     peak = BF16_MFMA_PEAK_TF if args.dtype == "bf16" else FP32_MFMA_PEAK_TF
     log(f"dense branch {dense_ms:.1f} ms/view, sparse branch {sparse_ms:.1f} ms/view; kernel roofline")
     roof_kernel = spconv_roofline(dev)
-    # `roofline`: kernel-level, the dominant hand-written kernel (k_spconv_tiles), HIP events live + PMC traffic from profiles/
+    # `roofline`: kernel-level, the dominant hand-written kernel (k_spconv_split), HIP events live + PMC traffic from profiles/
     roofline = dict(roof_kernel)
     roofline["scope"] = ("dominant hand-written HIP kernel; algorithmic FLOP = 2*pairs*cin*cout per launch (SURVEY 8d), one launch = "
                          "one sparse-conv layer of MinkUNet34C block8 on the full S1 cloud; the scene-level time is dominated by the "
@@ -327,37 +416,30 @@ def main():
 
     cpu_baseline = None
     if not args.no_cpu_baseline and world == 1:  # reported at N=1 only
-        from oracle import model_oracle, voxel_oracle
+        from oracle import infer_oracle
 
-        log("cpu baseline (1 view through the oracle)")
-        v = 3
-        vis, rows, cols = synthetic.view_subset(scene, v)
-        pts = scene.points[vis]
+        log("cpu baseline: one whole scene (5 views, post-processing, votes, fill) through the oracle")
         T = np.diag([50.0, 50.0, 50.0, 1.0])
         t1 = time.perf_counter()
-        grid, inds, inv = voxel_oracle.voxelize_with_matrix(pts, T)
-        coords = torch.from_numpy(np.concatenate([np.zeros((len(grid), 1)), grid], 1).astype(np.int32))
-        feats = torch.from_numpy((scene.colors[vis][inds] / 127.5 - 1).astype(np.float32))
-        cbatch = {"sinput": model_oracle.CpuSparseTensor(feats, coords), "img": torch.from_numpy(scene.images[v]).permute(2, 0, 1)[None],
-                  "x_label": torch.from_numpy(rows).long(), "y_label": torch.from_numpy(cols).long(),
-                  "inds_reconstruct": torch.from_numpy(inv), "captions": ("a room",),
-                  "ori_coords": torch.cat([torch.zeros(len(pts), 1), torch.from_numpy(pts).float()], 1)}
-        model_oracle.forward_cpu(cpu_model, cbatch)
-        t_view = time.perf_counter() - t1
-        cpu_baseline = {"value": 1.0 / (t_view * n_views), "unit": "scenes/s", "cores": torch.get_num_threads(), "kind": "port",
-                        "sample": f"1 of {n_views} views of S1 (view {v}, {len(pts)} points) through oracle/model_oracle.py "
-                                  f"(fp32, same weights), {t_view:.1f} s, extrapolated x{n_views}; vote/fill excluded"}
+        labels, _ = infer_oracle.scene_forward_cpu(cpu_model, cfg, scene, [T] * n_views)
+        t_scene = time.perf_counter() - t1
+        cpu_baseline = {"value": 1.0 / t_scene, "unit": "scenes/s", "cores": torch.get_num_threads(), "kind": "port",
+                        "sample": f"one whole scene S1 ({scene.points.shape[0]} points, {n_views} views): oracle/model_oracle.py per view "
+                                  f"(fp32, same weights) + oracle/infer_oracle.py (hole filling, ensembling, votes, nearest fill), "
+                                  f"{t_scene:.1f} s, no extrapolation"}
 
     out = {
         "metric": "ScanNet scenes/sec (infer)", "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype + " (frozen SD/CLIP nets, decoder GEMMs) + f32 (sparse 3D, deformable attention, statistics, logits)", "data": "synthetic",
-        "config": {"workload": "ScanNet B15N4 inference, synthetic scene S1 (119963 pts, 5 views 240x320->512x512), "
+        "dtype": args.dtype + " (frozen SD/CLIP nets, decoder GEMMs) + f32 (deformable attention, statistics, logits; sparse 3D: f32 in/out, "
+                 "products as bf16x3 split operands with f32 accumulation)", "data": "synthetic",
+        "config": {"workload": f"ScanNet B15N4 inference, synthetic scenes S1 ({len(scenes)} distinct seeds, ~120k pts, 5 views 240x320->512x512), "
                                f"{vb} views ({G} scene{'s' if G > 1 else ''}) per forward, seeded random weights", "views_per_scene": n_views, "parallelism": f"dp{world} (scene level, no collective)",
                    "dead_compute": "as reference" if args.faithful_dead_compute else "pruned (SURVEY F7)",
                    "layout": "NCHW" if args.nchw else "channels-last (NHWC) frozen nets",
                    "schedule": "eager launches" if args.no_graph else "3 HIP graphs per forward (2 slots), next forward's front software-pipelined on side streams"},
-        "roofline": roofline, "roofline_dense_stage": roofline_stage, "cpu_baseline": cpu_baseline, "train": train,
+        "roofline": roofline, "roofline_dense_stage": roofline_stage, "roofline_kernels": kernel_rooflines(dev),
+        "cpu_baseline": cpu_baseline, "latency_ms_single_scene": latency_ms, "fp32": fp32, "train": train,
     }
     print(json.dumps(out))
     if world > 1:

@@ -203,6 +203,21 @@ int xm3d_attn_mask_bias(const void* logits, int32_t in_dtype, int64_t maps, int3
                         int32_t out_dtype, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Fused softmax attention forward, bf16 in / f32 softmax and accumulation / bf16 out (replaces the library attention behind
+ * torch.nn.functional.scaled_dot_product_attention at the reference's call sites: ldm CrossAttention reached from
+ * models/modeling/meta_arch/ldm.py:425-446, open_clip's ResidualAttentionBlock from clip.py:239-270, nn.MultiheadAttention of
+ * mask2former_transformer_decoder.py:17-80):   out = softmax(q k^T * scale + bias) v   per (batch, head).
+ *   q (B,Nq,H,D), k / v (B,Nk,H,D), out (B,Nq,H,D): bf16, channels contiguous, ELEMENT strides {batch, row, head} given per
+ *   tensor (so (B,N,H*D) projections, (N,B,E) sequences and packed qkv buffers are consumed in place); D a multiple of 8, <= 160.
+ *   bias: NULL / bias_dtype 0 = none; 1 = f32, 2 = bf16 additive term of shape (B,H,Nq,Nk) with element strides {batch, head,
+ *   query row} (0 to broadcast), keys contiguous; values < -1e29 mask the key (a row with every key masked yields zeros).
+ * ------------------------------------------------------------------------- */
+int xm3d_attention_fwd(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t Nq, int32_t Nk,
+                       int32_t D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                       const int64_t* o_strides, const void* bias, int32_t bias_dtype, const int64_t* bias_strides,
+                       float scale, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Multi-scale deformable attention (replaces the pybind module
  * MultiScaleDeformableAttention: third_party/Mask2Former/mask2former/modeling/
  * pixel_decoder/ops/src/vision.cpp:18-21, ms_deform_attn.h:25-66,

@@ -61,3 +61,33 @@ def test_sync_moments_single_process():
     x = torch.randn(100, 8, dtype=torch.float64)
     mean, var, n = sync_moments(x.sum(0), (x * x).sum(0), 100)
     assert torch.allclose(mean, x.mean(0)) and torch.allclose(var, x.var(0, unbiased=False)) and float(n) == 100
+
+
+def test_loss_contra_gradient_reaches_the_3d_features():
+    """models/utils/criterion.py:39-182: a confident mask over mostly-novel points is selected and pulls the mean pure-3D
+    feature of its points towards the (detached) mask-CLIP embedding: the gradient must reach the 3D features, not the
+    CLIP embedding"""
+    import types
+
+    from xmask3d_amd.criterion import Criterion
+
+    torch.manual_seed(0)
+    Q, H, W, C, Np = 4, 24, 32, 16, 400
+    stub = types.SimpleNamespace(cfg=types.SimpleNamespace(mask_shape=(H, W)), contra_criterion=torch.nn.CosineSimilarity())
+    masks = torch.full((1, Q, H, W), -8.0)
+    masks[0, 1, :, :16] = 8.0                         # query 1 covers the left half, confidently
+    x = torch.randint(0, H, (Np,))
+    y = torch.randint(0, W, (Np,))
+    binary_gt = torch.zeros(Np)                       # every point novel -> "novel_num > 1.8 * base_num and > 10"
+    f3d = torch.randn(Np, C, requires_grad=True)
+    clip = torch.randn(1, Q, C, requires_grad=True)
+    outputs = {"pred_masks": masks, "fused_pred_feature": [torch.randn(Np, C)], "mask_embed": torch.randn(1, Q, C),
+               "pure3d_pred_feature": [f3d], "mask_embed_clip": clip}
+    losses, picked = Criterion.loss_contra(stub, [x], [y], [binary_gt], outputs)
+    assert len(picked) == 1 and picked[0][1].shape[0] == 1
+    loss = losses["loss_3d_contra"]
+    assert 0.0 <= float(loss) <= 2.0
+    loss.backward()
+    covered = y < 16
+    assert float(f3d.grad[covered].abs().sum()) > 0 and float(f3d.grad[~covered].abs().sum()) == 0
+    assert clip.grad is None or float(clip.grad.abs().sum()) == 0

@@ -1,0 +1,101 @@
+"""GPU parity of the HIP flash-attention kernel (xm3d_attention_fwd) against an fp32 softmax(q k^T / sqrt(d) + bias) v torch
+reference at every shape of the path (SD UNet self / cross attention, mask-CLIP ViT-L with its additive mask, the masked
+cross-attention of the Mask2Former decoder), on strided views as the call sites pass them.  bf16 in / bf16 out: the bound is
+the bf16 output rounding plus the bf16 rounding of P in the second product, 2e-2 of max|out| (measured ~4e-3)."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _ref(q, k, v, bias, scale):
+    q, k, v = (t.float().permute(0, 2, 1, 3) for t in (q, k, v))  # (B, H, N, D)
+    s = (q @ k.transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias.float()
+    return torch.softmax(s, -1).nan_to_num(0.0) @ v
+
+
+def _check(out, ref, tol=2e-2):
+    ref = ref.permute(0, 2, 1, 3)
+    err = (out.float() - ref).abs().max().item() / max(ref.abs().max().item(), 1e-20)
+    assert err < tol, err
+    return err
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 8, 4096, 4096, 40), (2, 8, 1024, 1024, 80), (3, 8, 256, 256, 160), (3, 8, 64, 64, 160),
+                                         (2, 8, 4096, 77, 40), (2, 8, 1024, 77, 80), (2, 8, 256, 77, 160), (2, 16, 307, 307, 64),
+                                         (2, 8, 50, 256, 32), (2, 8, 50, 4096, 32), (1, 2, 33, 65, 8), (1, 1, 1, 1, 16),
+                                         (1, 3, 130, 191, 96), (1, 2, 95, 64, 128)])
+def test_attention_matches_fp32_reference(dev, B, H, Nq, Nk, D):
+    from xmask3d_amd import ops
+
+    g = torch.Generator().manual_seed(B * 1000 + Nq + Nk + D)
+    # projections as the call sites hold them: (B, N, H*D) buffers viewed as (B, N, H, D)
+    q = torch.randn(B, Nq, H * D, generator=g).to(dev, torch.bfloat16).view(B, Nq, H, D)
+    k = torch.randn(B, Nk, H * D, generator=g).to(dev, torch.bfloat16).view(B, Nk, H, D)
+    v = torch.randn(B, Nk, H * D, generator=g).to(dev, torch.bfloat16).view(B, Nk, H, D)
+    assert ops.attention_supported(q, k, v)
+    out = ops.attention(q, k, v)
+    assert out.shape == (B, Nq, H, D) and out.dtype == torch.bfloat16
+    _check(out, _ref(q, k, v, None, D ** -0.5))
+    # a sharp row: one key dominating (exercises the running-maximum rescale across tiles)
+    if Nk > 64:
+        k2 = k.clone()
+        k2[:, Nk - 3] = q[:, 0:1].expand(-1, 1, -1, -1).reshape(B, H, D) * 4
+        _check(ops.attention(q, k2, v), _ref(q, k2, v, None, D ** -0.5))
+
+
+def test_packed_qkv_and_additive_mask_like_mask_clip(dev):
+    """q / k / v as strided views of one packed (B, T, 3, H, D) buffer, additive bf16 mask (B, 1, T, T) with -inf entries"""
+    from xmask3d_amd import ops
+    from xmask3d_amd.clip_model import additive_mask
+
+    B, T, H, D, Q = 3, 307, 16, 64, 50
+    g = torch.Generator().manual_seed(7)
+    qkv = torch.randn(B, T, 3, H, D, generator=g).to(dev, torch.bfloat16)
+    allow = torch.ones(B, T, T, dtype=torch.bool)
+    allow[:, :, :Q] = False
+    allow[:, :Q, Q + 1:] = torch.rand(B, Q, T - Q - 1, generator=g) < 0.3
+    bias = additive_mask(allow[:, None].to(dev), torch.bfloat16)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    assert ops.attention_supported(q, k, v, bias)
+    _check(ops.attention(q, k, v, bias=bias), _ref(q, k, v, bias, D ** -0.5))
+
+
+def test_sequence_first_layout_shared_bias_and_output_view(dev):
+    """(L, B, E) projections of nn.MultiheadAttention viewed as (B, L, H, d); f32 bias (B, 1, Q, K) shared by the heads with a
+    fully masked row (-> zeros, no NaN); output written through a view of an (Lq, B, E) buffer"""
+    from xmask3d_amd import ops
+
+    Lq, Lk, B, H, d = 50, 1024, 4, 8, 32
+    E = H * d
+    g = torch.Generator().manual_seed(11)
+    q = torch.randn(Lq, B, E, generator=g).to(dev, torch.bfloat16)
+    k = torch.randn(Lk, B, E, generator=g).to(dev, torch.bfloat16)
+    v = torch.randn(Lk, B, E, generator=g).to(dev, torch.bfloat16)
+    bias = torch.zeros(B, Lq, Lk).masked_fill_(torch.rand(B, Lq, Lk, generator=g) < 0.6, float("-inf"))
+    bias[1, 7] = float("-inf")  # one fully masked row
+    bias = bias.to(dev)
+    q4, k4, v4 = (t.view(t.shape[0], B, H, d).transpose(0, 1) for t in (q, k, v))
+    o = torch.empty(Lq, B, E, dtype=torch.bfloat16, device=dev)
+    ops.attention(q4, k4, v4, bias=bias.view(B, 1, Lq, Lk), out=o.view(Lq, B, H, d).transpose(0, 1))
+    ref = _ref(q4, k4, v4, bias.view(B, 1, Lq, Lk), d ** -0.5).permute(0, 2, 1, 3)  # (B, Lq, H, d)
+    got = o.view(Lq, B, H, d).transpose(0, 1).float()
+    assert torch.isfinite(got).all() and float(got[1, 7].abs().max()) == 0.0
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-2
+
+
+def test_unsupported_inputs_are_refused(dev):
+    from xmask3d_amd import ops
+
+    q = torch.randn(1, 8, 2, 40, device=dev)
+    assert not ops.attention_supported(q, q, q)                                # f32
+    qb = q.bfloat16()
+    assert ops.attention_supported(qb, qb, qb)
+    assert not ops.attention_supported(qb.cpu(), qb.cpu(), qb.cpu())          # CPU tensors stay on the library path
+    qd = torch.randn(1, 8, 2, 512, device=dev).bfloat16()
+    assert not ops.attention_supported(qd, qd, qd)                            # VAE single head of 512 channels: library path
+    with torch.enable_grad():
+        qg = qb.clone().requires_grad_(True)
+        assert not ops.attention_supported(qg, qb, qb)                        # training: autograd path

@@ -73,7 +73,12 @@ def point_logits(fused, outputs):
 
 def stage_report(out, b, sel, ref):
     """errors of batch entry b of a device forward (`sel` = its point range) against the oracle outputs of that view"""
-    rep = {k: _rel(out[k][b], ref[k][0]) for k in ("pred_masks", "mask_embed", "mask_embed_clip")}
+    rep = {k: _rel(out[k][b], ref[k][0]) for k in ("pred_masks", "mask_embed")}
+    # mask-CLIP thresholds every mask per 14x14 patch (clip.py:272-310): a mask logit within rounding of the threshold flips a
+    # patch of ONE query's attention mask - a discrete event.  Bound the queries that did not flip, count the ones that did.
+    ce = (out["mask_embed_clip"][b].float().cpu() - ref["mask_embed_clip"][0]).abs().amax(-1) / ref["mask_embed_clip"][0].abs().max()
+    rep["mask_embed_clip"] = ce.sort().values[: ce.numel() - 2].max().item()      # all but the two worst queries
+    rep["clip_queries_flipped"] = float((ce > 10 * max(rep["mask_embed_clip"], 1e-6)).sum())
     rep["pred_3d"] = _rel(out["pred_3d"][sel], ref["pred_3d"])
     rep["pred_logits_abs"] = (out["pred_logits"][b].float().cpu() - ref["pred_logits"][0]).abs().max().item()
     m_g, m_r = out["final_mask_3d"][b].cpu(), ref["final_mask_3d"][0]          # (Q, Np) bool, all Q rows on both sides
@@ -100,12 +105,15 @@ def _forward_group(model, sds, vox):
     return batch, out
 
 
-# fp32 bounds (relative to the tensor's max magnitude unless "_abs"); measured values in DESIGN.md §5 "parity budgets"
-FP32 = {"pred_3d": 2e-4, "pred_masks": 1e-3, "mask_embed": 1e-3, "mask_embed_clip": 2e-3, "pred_logits_abs": 1e-3,
-        "fused_rel": 5e-4, "point_logits_abs": 1e-3}
-# bench configuration (bf16 frozen nets + bf16 head GEMMs): budgets
-BF16 = {"pred_3d": 2e-4, "pred_masks": 8e-2, "mask_embed": 8e-2, "mask_embed_clip": 8e-2, "pred_logits_abs": 0.6,
-        "fused_rel": 8e-2, "point_logits_abs": 0.6}
+# fp32 bounds (relative to the tensor's max magnitude unless "_abs").  Measured (gpurun_out/r2_parity2.log):
+# pred_3d 5e-6, pred_masks 2e-4, mask_embed 4e-4, mask_embed_clip 2e-6, pred_logits 3e-4, fused 3e-5, per-point logits 4e-5
+# - eager and graph replay alike.  north_star: per-point logits within 1e-3.
+FP32 = {"pred_3d": 5e-5, "pred_masks": 1e-3, "mask_embed": 1e-3, "mask_embed_clip": 1e-4, "pred_logits_abs": 1e-3,
+        "fused_rel": 2e-4, "point_logits_abs": 2e-4}
+# bench configuration (bf16 frozen nets + bf16 head GEMMs).  Measured: pred_masks 5.1e-2, mask_embed 6.3e-2, mask_embed_clip
+# 3.9e-2, pred_logits 4.2e-2, fused 2.0e-2, per-point logits 1.8e-2 (scale*cos, scale ~14), ownership 98.3 %, labels 100 %.
+BF16 = {"pred_3d": 5e-5, "pred_masks": 8e-2, "mask_embed": 1e-1, "mask_embed_clip": 7e-2, "pred_logits_abs": 8e-2,
+        "fused_rel": 4e-2, "point_logits_abs": 4e-2}
 
 
 @pytest.mark.parametrize("mode", ["fp32_eager", "fp32_graph_nhwc", "bf16_bench"])
@@ -128,6 +136,7 @@ def test_configuration_matches_oracle_per_stage(dev, setup, mode):
         print(f"[parity {mode} scene {si} view {v}] " + " ".join(f"{k}={x:.3e}" for k, x in rep.items()))
         for k, x in rep.items():
             worst[k] = max(worst.get(k, 0.0), x) if not k.endswith("agree") else min(worst.get(k, 1.0), x)
+    assert worst["clip_queries_flipped"] <= 2
     for k, bound in bounds.items():
         assert worst[k] <= bound, f"{mode}: {k} = {worst[k]:.3e} > {bound:.1e}"
     assert worst["binary_agree"] > 0.999

@@ -81,8 +81,15 @@ def test_batchnorm_function_matches_torch(dev):
     assert _rel(y2, ref2.detach()) < 1e-5 and _rel(x2.grad, xr2.grad) < 1e-4
 
 
-def test_minkunet_training_backward_matches_oracle(dev):
+@pytest.mark.parametrize("algo", ["tiles", "split"])
+def test_minkunet_training_backward_matches_oracle(dev, algo, monkeypatch):
+    """whole-network backward (29 convs, training-mode BatchNorm) against autograd of the CPU oracle.  The problem is badly
+    conditioned on purpose-small inputs (BatchNorm over a few dozen rows at tensor stride 16 amplifies a 1e-6 forward
+    perturbation by ~1e4): the exact-f32 kernels (algo 3) hold 2e-2, the split-operand kernels (algo 4, 5e-6 per conv)
+    1e-1; the per-conv dgrad / wgrad tests above hold both to 2e-5 / 1e-4."""
     from xmask3d_amd import me_compat as ME
+
+    monkeypatch.setenv("XM3D_SPCONV_ALGO", algo)
     from xmask3d_amd.mink_unet import mink_unet
 
     torch.manual_seed(3)
@@ -103,7 +110,7 @@ def test_minkunet_training_backward_matches_oracle(dev):
         if q.grad is None:
             continue
         assert p.grad is not None, k
-        assert _rel(p.grad, q.grad) < 2e-2, k  # 29 convs deep, f32, atomics in wgrad
+        assert _rel(p.grad, q.grad) < (2e-2 if algo == "tiles" else 1e-1), k  # 29 convs deep, f32, atomics in wgrad
         checked += 1
     assert checked > 60
 
@@ -139,6 +146,32 @@ def test_full_training_step(dev):
     assert frozen == []  # no weight-grads for the frozen SD / CLIP nets
     opt.step()
     assert not torch.equal(before, model.criterion.fuser.linear.weight.detach())
+
+
+def test_contrastive_loss_enters_the_objective_from_start_contra(dev):
+    """run/train.py:292-307: before cfg.start_contra the mask-level 3D contrastive loss is off (weight 0, not computed); from
+    that epoch on it is in the returned losses with cfg.loss_weight.loss_3d_contra and its gradient reaches pc_decoder"""
+    from xmask3d_amd import driver, pipeline, synthetic
+    from xmask3d_amd.config import load_cfg_from_cfg_file
+    from xmask3d_amd.xmask3d import XMASK3d
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_cfg_from_cfg_file(os.path.join(root, "configs", "xmask3d_scannet_B15N4.yaml"))
+    assert cfg.mask_contra_3d and cfg.start_contra == 50 and cfg.loss_weight["loss_3d_contra"] == 0.5
+    torch.manual_seed(5557)
+    model = XMASK3d(cfg).to(dev).train()
+    sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
+    batch = pipeline.build_train_batch(sd, [2], pipeline.default_voxelizer(device=dev), seed=5557)
+    driver.set_contra_schedule(model, cfg, cfg.start_contra - 1)
+    assert model.criterion.mask_contra_3d is False and model.criterion.weight_dict["loss_3d_contra"] == 0
+    losses, _ = model(batch)
+    assert "loss_3d_contra" not in losses  # not computed at all before start_contra
+    driver.set_contra_schedule(model, cfg, cfg.start_contra)
+    assert model.criterion.mask_contra_3d is True and model.criterion.weight_dict["loss_3d_contra"] == 0.5
+    losses, _ = model(batch)
+    assert "loss_3d_contra" in losses and torch.isfinite(losses["loss_3d_contra"])
+    # (with seeded random weights no mask passes the novel / base selection of criterion.py:186-215, so the loss takes its
+    # constant fallback here; that its gradient reaches the 3D features once masks are selected: tests/test_criterion.py)
 
 
 def test_graphed_unet_forward_backward_matches_eager(dev):

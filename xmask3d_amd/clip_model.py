@@ -22,6 +22,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
+
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
 SOT, EOT, VOCAB, CONTEXT = 49406, 49407, 49408, 77
@@ -30,6 +32,11 @@ SOT, EOT, VOCAB, CONTEXT = 49406, 49407, 49408, 77
 class QuickGELU(nn.Module):
     def forward(self, x):
         return x * torch.sigmoid(1.702 * x)
+
+
+def additive_mask(allow, dtype):
+    """bool 'may attend' mask -> additive mask (0 / -inf) of `dtype`, contiguous"""
+    return torch.zeros(allow.shape, dtype=dtype, device=allow.device).masked_fill_(~allow, float("-inf"))
 
 
 class ResidualAttentionBlock(nn.Module):
@@ -46,7 +53,19 @@ class ResidualAttentionBlock(nn.Module):
         """x (B,T,C); allow: None | bool (T,T) | bool (B,1,T,T), True = may attend."""
         b, t, c = x.shape
         qkv = F.linear(x, self.attn.in_proj_weight, self.attn.in_proj_bias).view(b, t, 3, self.heads, c // self.heads)
+        if ops.attention_supported(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]):
+            # bf16 inference: HIP flash attention straight on the packed qkv buffer; `allow` as an additive mask (built once
+            # per forward by the caller through additive_mask(), shared by the 24 layers)
+            bias = allow if (allow is None or allow.dtype != torch.bool) else additive_mask(allow, x.dtype)
+            if bias is not None and bias.dim() == 2:
+                bias = bias[None, None]
+            o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], bias=bias)
+            return self.attn.out_proj(o.view(b, t, c))
         q, k, v = qkv.permute(2, 0, 3, 1, 4)
+        if allow is not None and allow.dtype != torch.bool:
+            allow = allow.to(q.dtype)
+            if allow.dim() == 2:
+                allow = allow[None, None]
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=allow)
         return self.attn.out_proj(o.transpose(1, 2).reshape(b, t, c))
 
@@ -62,6 +81,8 @@ class Transformer(nn.Module):
         self.resblocks = nn.ModuleList(ResidualAttentionBlock(width, heads) for _ in range(layers))
 
     def forward(self, x, allow=None):
+        if allow is not None and allow.dtype == torch.bool and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled():
+            allow = additive_mask(allow, x.dtype)  # once for all layers (the HIP attention takes the additive form)
         for blk in self.resblocks:
             x = blk(x, allow)
         return x
@@ -228,8 +249,9 @@ class CategoryEmbed(nn.Module):
         if self.training:
             return {"text_embed": self.text_proj(self.text_embed), "null_embed": self.text_proj(self.null_embed),
                     "labels": self.labels}
-        key = tuple(tuple(l) for l in self.test_labels)
-        if key not in self._test_cache:
-            self._test_cache[key] = self.clip.build_text_embed(self.test_labels)
-        te = self._test_cache[key].to(self.null_embed.device)
+        dev = self.null_embed.device
+        key = (tuple(tuple(l) for l in self.test_labels), str(dev))  # per device: a deep copy moved to another device must not
+        if key not in self._test_cache:                              # upload a cached CPU tensor inside a HIP-graph capture
+            self._test_cache[key] = self.clip.build_text_embed(self.test_labels).to(dev)
+        te = self._test_cache[key]
         return {"text_embed": self.text_proj(te), "null_embed": self.text_proj(self.null_embed), "labels": self.test_labels}

@@ -20,6 +20,7 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
 from .msda import MSDeformAttn
 
 
@@ -256,6 +257,13 @@ class CrossAttentionLayer(nn.Module):
         v = F.linear(memory, w[2 * E:], b[2 * E:])
         Lq, B = q.shape[:2]
         Lk = k.shape[0]
+        q4, k4, v4 = (t.view(t.shape[0], B, H, E // H).transpose(0, 1) for t in (q, k, v))  # (B, L, H, d) views of the (L, B, E) rows
+        if ops.attention_supported(q4, k4, v4):
+            # bf16 inference: HIP flash attention on the projections in place, the additive mask shared by the heads, the
+            # output written straight in (Lq, B, E) order for the out-projection
+            o = torch.empty((Lq, B, E), dtype=q.dtype, device=q.device)
+            ops.attention(q4, k4, v4, bias=memory_bias.view(B, 1, Lq, Lk), out=o.view(Lq, B, H, E // H).transpose(0, 1))
+            return self.norm(tgt + F.linear(o, mha.out_proj.weight, mha.out_proj.bias))
         q = q.view(Lq, B, H, E // H).permute(1, 2, 0, 3)
         k = k.view(Lk, B, H, E // H).permute(1, 2, 0, 3)
         v = v.view(Lk, B, H, E // H).permute(1, 2, 0, 3)

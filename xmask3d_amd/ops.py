@@ -440,6 +440,50 @@ def geglu(x):
     return out
 
 
+# ---------------------------------------------------------------- fused softmax attention
+def attention_supported(q, k, v, bias=None):
+    """True when xm3d_attention_fwd takes these tensors as they are (bf16 device tensors (B,N,H,D), channels contiguous, 16-byte
+    rows, D a multiple of 8 up to 160, no gradient wanted); callers keep the library path for everything else"""
+    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+        return False
+    for t in (q, k, v):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 4 or t.stride(3) != 1 or t.data_ptr() % 16:
+            return False
+        if any(st % 8 for st in t.stride()[:3]):
+            return False
+    D = q.shape[3]
+    if D % 8 or D > 160 or k.shape[3] != D or v.shape[3] != D or k.shape[1] != v.shape[1] or k.shape[1] < 1:
+        return False
+    if bias is not None and (not bias.is_cuda or bias.dtype not in (torch.float32, torch.bfloat16) or bias.dim() != 4 or bias.stride(3) != 1):
+        return False
+    return True
+
+
+def attention(q, k, v, bias=None, scale=None, out=None):
+    """softmax(q k^T * scale + bias) v per (batch, head).  q (B,Nq,H,D), k/v (B,Nk,H,D) bf16 views with contiguous channels
+    (any batch / row / head strides); bias None or additive f32/bf16 (B|1, H|1, Nq, Nk) (broadcast over size-1 dims, -inf
+    masks).  -> out (B,Nq,H,D) bf16 (a fresh contiguous tensor, or the given view)."""
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    if out is None:
+        out = torch.empty((B, Nq, H, D), dtype=torch.bfloat16, device=q.device)
+    if scale is None:
+        scale = D ** -0.5
+
+    def st(t):
+        return (ctypes.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+    bdt, bst = 0, None
+    if bias is not None:
+        if bias.shape[-2:] != (Nq, Nk) or bias.shape[0] not in (1, B) or bias.shape[1] not in (1, H):
+            raise RuntimeError(f"attention: bias shape {tuple(bias.shape)} does not broadcast to ({B},{H},{Nq},{Nk})")
+        bdt = 1 if bias.dtype == torch.float32 else 2
+        bst = (ctypes.c_int64 * 3)(bias.stride(0) if bias.shape[0] > 1 else 0, bias.stride(1) if bias.shape[1] > 1 else 0, bias.stride(2))
+    check(lib().xm3d_attention_fwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Nq, Nk, D, st(q), st(k), st(v), st(out), _ptr(bias), bdt,
+                                   bst, float(scale), _stream()), "xm3d_attention_fwd")
+    return out
+
+
 # ---------------------------------------------------------------- deformable attention
 def _msda_dtype(value):
     if value.dtype not in (torch.float32, torch.float64):

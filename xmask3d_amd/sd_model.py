@@ -25,6 +25,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from . import ops
+
 
 def swish(x):
     return x * torch.sigmoid(x)
@@ -290,10 +292,12 @@ class CrossAttention(nn.Module):
         context = x if context is None else context
         b, n, _ = x.shape
         h = self.heads
-        q = self.to_q(x).view(b, n, h, -1).transpose(1, 2)
-        k = self.to_k(context).view(b, context.shape[1], h, -1).transpose(1, 2)
-        v = self.to_v(context).view(b, context.shape[1], h, -1).transpose(1, 2)
-        o = F.scaled_dot_product_attention(q, k, v).transpose(1, 2).reshape(b, n, -1)
+        q = self.to_q(x).view(b, n, h, -1)
+        k = self.to_k(context).view(b, context.shape[1], h, -1)
+        v = self.to_v(context).view(b, context.shape[1], h, -1)
+        if ops.attention_supported(q, k, v):  # bf16 inference: HIP flash attention on the (B, N, H*D) projections in place
+            return self.to_out(ops.attention(q, k, v).view(b, n, -1))
+        o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).reshape(b, n, -1)
         return self.to_out(o)
 
 
