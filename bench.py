@@ -30,6 +30,7 @@ import torch
 FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
 BF16_MFMA_PEAK_TF = 2500.0  # dense bf16
 HBM_PEAK_GBPS = 8000.0      # HBM3E spec (6.3 TB/s measured copy)
+L2_PEAK_GBPS = 34500.0      # aggregate L2 rate (MI355X_MICROARCH.md, L2 section)
 SPCONV_PMC_TRAFFIC_BYTES = None  # filled from profiles/r02_roofline_spconv_pmc.txt once collected
 DENSE_TFLOP_PER_VIEW_MIN = 2.83  # SURVEY.md §8d, dead compute pruned
 DENSE_TFLOP_PER_VIEW_REF = 4.79  # as the reference computes
@@ -115,10 +116,11 @@ def kernel_rooflines(dev):
     ms = event_ms(lambda: ops.msda_forward(value, shapes, lsi, loc, w), 10)
     gathered = B * S * H * L * P * 4 * D * 4
     comp = (value.numel() + loc.numel() + w.numel() + B * S * H * D) * 4
-    out.append({"kernel": "xm3d::k_msda_fwd<float,4>", "bound": "hbm", "achieved": gathered / (ms * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS,
-                "unit": "GB/s", "frac": gathered / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "avg_launch_us": ms * 1e3,
-                "algorithmic_bytes": gathered, "compulsory_bytes": comp,
-                "note": "bytes = bilinear taps gathered (value tensor is L2 resident: 5.5 MB per view); 20 views"})
+    out.append({"kernel": "xm3d::k_msda_fwd<float,4>", "bound": "l2", "achieved": gathered / (ms * 1e-3) / 1e9, "peak": L2_PEAK_GBPS,
+                "unit": "GB/s", "frac": gathered / (ms * 1e-3) / 1e9 / L2_PEAK_GBPS, "avg_launch_us": ms * 1e3,
+                "algorithmic_bytes": gathered, "compulsory_bytes": comp, "compulsory_GBps": comp / (ms * 1e-3) / 1e9,
+                "note": "bytes = bilinear taps gathered (the value tensor, 5.5 MB per view, is L2 / Infinity-Cache resident, so the "
+                        "gather is priced against the aggregate L2 rate, 34.5 TB/s); 20 views"})
     # GroupNorm (statistics + apply), channels-last bf16, the VAE's 256^2 x 256-channel maps, 5 views: 3 passes over the tensor
     x = torch.randn(5, 256, 256, 256, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
     gw, gb = torch.ones(256, device=dev, dtype=torch.bfloat16), torch.zeros(256, device=dev, dtype=torch.bfloat16)
@@ -364,11 +366,14 @@ def main():
     # the same pipeline with every net in fp32 (the reference's arithmetic; BASELINE config 2 names bf16, hence not `value`)
     fp32 = None
     if args.dtype == "bf16" and args.fp32_steps > 0 and graphed:
+        # one scene (5 views) per forward: the shipped MIOpen find-db covers the fp32 convolutions at that batch (20-view fp32
+        # shapes would each trigger a find at capture time: minutes of set-up for a secondary number)
         m32 = pipeline.make_inference_model(cpu_model, dev, torch.float32, channels_last=not args.nchw, graphs=True)
-        capture(m32, args.fp32_steps)
-        run(m32, 1)
-        dt32 = timed(m32, args.fp32_steps)
+        capture(m32, args.fp32_steps, 1)
+        run(m32, 1, 1)
+        dt32 = timed(m32, args.fp32_steps, 1)
         fp32 = {"value": world * args.fp32_steps / dt32, "unit": "scenes/s", "ms_per_step": dt32 / args.fp32_steps * 1e3, "steps": args.fp32_steps,
+                "scenes_per_forward": 1,
                 "dtype": "f32 everywhere (sparse 3D on the bf16x3 split-operand MFMA kernel, f32 accumulate)"}
         del m32
         torch.cuda.empty_cache()

@@ -263,6 +263,18 @@ int xm3d_mask_owner(const float* logits, const float* score, const uint8_t* keep
                     void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Batched linear sum assignment (replaces cost.cpu() + scipy.optimize.linear_sum_assignment in the reference's matcher,
+ * third_party/Mask2Former/mask2former/modeling/matcher.py:95-156, called ten times per training iteration):
+ *   cost (n_mat, Q, T_max) f32 on the device, matrix m uses its first n_targets[m] columns (n_targets (n_mat) i32, device),
+ *   1 <= Q <= 64, T_max <= 256.  Per matrix: min(Q, n_targets[m]) (query, target) pairs, every query and every target at most
+ *   once, of minimum summed cost (scipy's rectangular semantics; f64 arithmetic like scipy; with tied costs one of the optima).
+ *   out_q / out_t (n_mat, T_max) i64: the matched pairs sorted by ascending query index (scipy's order) in the first
+ *   min(Q, n_targets[m]) slots; the remaining slots are left untouched (callers pre-fill them).
+ * ------------------------------------------------------------------------- */
+int xm3d_linear_sum_assignment(const float* cost, int64_t n_mat, int32_t Q, int32_t T_max, const int32_t* n_targets,
+                               int64_t* out_q, int64_t* out_t, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Exact 1-nearest-neighbour index (replaces sklearn.neighbors.KDTree(...).query(k=1) in run/infer.py:523-553,
  * :682-694): query (n,3) f32, ref (m,3) f32, out (n) i64 = arg-min squared distance, lowest index on ties.
  * ref_valid (m) u8 or NULL: reference points with 0 are ignored (if no reference point is valid the result is 0).

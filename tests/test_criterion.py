@@ -91,3 +91,14 @@ def test_loss_contra_gradient_reaches_the_3d_features():
     covered = y < 16
     assert float(f3d.grad[covered].abs().sum()) > 0 and float(f3d.grad[~covered].abs().sum()) == 0
     assert clip.grad is None or float(clip.grad.abs().sum()) == 0
+
+
+def test_matcher_assign_on_cpu_is_scipy():
+    from scipy.optimize import linear_sum_assignment
+    from xmask3d_amd.criterion import HungarianMatcher
+
+    torch.manual_seed(1)
+    costs = [torch.randn(50, 7), torch.randn(50, 1)]
+    for C, (i, j) in zip(costs, HungarianMatcher.assign(costs)):
+        ri, ci = linear_sum_assignment(C)
+        assert i.tolist() == ri.tolist() and j.tolist() == ci.tolist()

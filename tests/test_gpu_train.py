@@ -148,6 +148,35 @@ def test_full_training_step(dev):
     assert not torch.equal(before, model.criterion.fuser.linear.weight.detach())
 
 
+@pytest.mark.parametrize("name,n_train", [("xmask3d_scannet_B12N7", 12), ("xmask3d_scannet_B170N30", 170)])
+def test_training_step_other_benchmark_configs(dev, name, n_train):
+    """BASELINE.json configs 4 and 5 in TRAINING: one full iteration (37 weighted losses, backward, AdamW) with the 12-class
+    and the 170-class heads; bf16 frozen nets (config 5 names fp16: on gfx950 bf16 has the same MFMA rate and the exponent
+    range the SD VAE activations need; the HIP GroupNorm / attention kernels are instantiated for bf16)"""
+    from xmask3d_amd import driver, pipeline, synthetic
+    from xmask3d_amd.config import load_cfg_from_cfg_file
+    from xmask3d_amd.xmask3d import XMASK3d
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_cfg_from_cfg_file(os.path.join(root, "configs", name + ".yaml"))
+    assert cfg.classes == n_train
+    torch.manual_seed(3)
+    with torch.device(dev):
+        model = XMASK3d(cfg, dense_dtype=torch.bfloat16)
+    model = model.to(dev).train()
+    opt = driver.build_optimizer(model, cfg)
+    sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
+    batch = pipeline.build_train_batch(sd, [0], pipeline.default_voxelizer(device=dev), seed=3, n_classes=n_train)
+    before = model.pc_decoder.decoder.weight.detach().clone()
+    losses, outputs = model(batch)
+    assert outputs["pred_logits"].shape[-1] == n_train + 1 and "loss_mask_8" in losses
+    total = sum(losses.values())
+    assert torch.isfinite(total)
+    total.backward()
+    opt.step()
+    assert not torch.equal(before, model.pc_decoder.decoder.weight.detach())
+
+
 def test_contrastive_loss_enters_the_objective_from_start_contra(dev):
     """run/train.py:292-307: before cfg.start_contra the mask-level 3D contrastive loss is off (weight 0, not computed); from
     that epoch on it is in the returned losses with cfg.loss_weight.loss_3d_contra and its gradient reaches pc_decoder"""

@@ -34,6 +34,12 @@ reps = int(sys.argv[1]) if len(sys.argv) > 1 else 10
 if which in ("both", "full"):
     coords, feats, _ = prep(sc.points, sc.colors)
     run(coords, feats, reps, "S1-full")
+if which in ("batch",):  # the bench forward: 4 scenes x 5 views in one batch
+    from xmask3d_amd import pipeline
+    sd = pipeline.SceneOnDevice(sc, dev)
+    vox = pipeline.default_voxelizer(device=dev)
+    b = pipeline.build_group_batch([(sd, list(range(5)))] * 4, vox, [[T] * 5] * 4)
+    run(b["coords"], b["sinput"].F, reps, "S1-batch20")
 if which in ("both", "view"):
     vis, r, c = synthetic.view_subset(sc, 3)
     coords, feats, _ = prep(sc.points[vis], sc.colors[vis])

@@ -77,9 +77,10 @@ class HungarianMatcher(nn.Module):
         self.cost_class, self.cost_mask, self.cost_dice, self.num_points = cost_class, cost_mask, cost_dice, num_points
 
     @torch.no_grad()
-    def forward(self, outputs, targets):
+    def cost_matrices(self, outputs, targets):
+        """matcher.py:103-149: per image the (Q, T) matching cost 5*BCE + 5*dice + 2*(-prob) on num_points random points"""
         bs, num_queries = outputs["pred_logits"].shape[:2]
-        indices = []
+        costs = []
         for b in range(bs):
             out_prob = outputs["pred_logits"][b].softmax(-1)
             cost_class = -out_prob[:, targets[b]["labels"]]
@@ -89,17 +90,48 @@ class HungarianMatcher(nn.Module):
             tgt = point_sample(tgt_mask, pts.repeat(tgt_mask.shape[0], 1, 1), align_corners=False).squeeze(1)
             out = point_sample(out_mask, pts.repeat(out_mask.shape[0], 1, 1), align_corners=False).squeeze(1)
             C = self.cost_mask * batch_sigmoid_ce_loss(out, tgt) + self.cost_class * cost_class + self.cost_dice * batch_dice_loss(out, tgt)
-            i, j = linear_sum_assignment(C.reshape(num_queries, -1).cpu())
-            indices.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
-        dev = outputs["pred_logits"].device
-        if dev.type != "cpu" and indices:
-            # one upload for the whole batch: the losses index device tensors with these, and every index tensor left on the
-            # host would cost its own blocking host->device copy (seven per decoder layer)
-            sizes = [len(i) for i, _ in indices]
-            flat = torch.cat([torch.cat(p) for p in indices]).to(dev)
-            parts = flat.split([2 * n for n in sizes])
-            indices = [(p[:n], p[n:]) for p, n in zip(parts, sizes)]
-        return indices
+            costs.append(C.reshape(num_queries, -1))
+        return costs
+
+    @staticmethod
+    def assign(costs):
+        """list of (Q, T_i) cost matrices -> list of (query idx, target idx) int64 pairs sorted by query (scipy's order).
+        Device matrices: ONE xm3d_linear_sum_assignment launch for all of them, no host round trip (the reference moves each
+        matrix to the host for scipy, matcher.py:151-152); CPU matrices: scipy, as the reference."""
+        if not costs:
+            return []
+        if costs[0].device.type == "cpu":
+            out = []
+            for C in costs:
+                i, j = linear_sum_assignment(C)
+                out.append((torch.as_tensor(i, dtype=torch.int64), torch.as_tensor(j, dtype=torch.int64)))
+            return out
+        from . import ops
+
+        Q = costs[0].shape[0]
+        sizes = [int(C.shape[1]) for C in costs]
+        Tm = max(max(sizes), 1)
+        if Q > 64 or Tm > 256:
+            raise RuntimeError(f"HungarianMatcher.assign: Q={Q}, T={Tm} outside the device solver's range (Q <= 64, T <= 256)")
+        dev = costs[0].device
+        stack = torch.zeros((len(costs), Q, Tm), dtype=torch.float32, device=dev)
+        for m, C in enumerate(costs):
+            stack[m, :, : sizes[m]] = C
+        key = (tuple(sizes), str(dev))
+        cache = HungarianMatcher._nt_cache
+        if key not in cache:  # the target counts of a batch repeat for all ten decoder outputs: one upload per distinct tuple
+            if len(cache) > 64:
+                cache.clear()
+            host = torch.tensor(sizes, dtype=torch.int32).pin_memory()  # pinned + non_blocking: the host does not wait for the stream
+            cache[key] = (host.to(dev, non_blocking=True), host)
+        oq, ot = ops.linear_sum_assignment(stack, cache[key][0])
+        return [(oq[m, : min(n, Q)], ot[m, : min(n, Q)]) for m, n in enumerate(sizes)]
+
+    _nt_cache = {}
+
+    @torch.no_grad()
+    def forward(self, outputs, targets):
+        return self.assign(self.cost_matrices(outputs, targets))
 
 
 def mask_mapper(x_list, y_list, masks, mask_embeds, pred_3ds, fuser, fc1, fc2, cfg):
@@ -293,7 +325,14 @@ class Criterion(nn.Module):
         import torch.distributed as dist
 
         no_aux = {k: v for k, v in outputs.items() if k != "aux_outputs"}
-        indices = self.matcher(no_aux, targets)
+        aux_list = list(outputs.get("aux_outputs", [])) if self.training else []
+        # all matchings of the iteration (main + nine auxiliary decoder outputs) in one batched device launch
+        costs = self.matcher.cost_matrices(no_aux, targets)
+        nb = len(costs)
+        for aux in aux_list:
+            costs += self.matcher.cost_matrices(aux, targets)
+        matched = self.matcher.assign(costs)
+        indices = matched[:nb]
         num_masks = torch.as_tensor([sum(len(t["labels"]) for t in targets)], dtype=torch.float,
                                     device=outputs["pred_masks"].device)
         world = 1
@@ -317,8 +356,8 @@ class Criterion(nn.Module):
             lc, final_2d_mask = self.loss_contra(x_list, y_list, bg_list, outputs)
             losses.update(lc)
             outputs["final_pred_mask"] = final_2d_mask
-        for i, aux in enumerate(outputs.get("aux_outputs", [])):
-            idx = self.matcher(aux, targets)
+        for i, aux in enumerate(aux_list):
+            idx = matched[nb * (i + 1): nb * (i + 2)]
             for loss in self.losses:
                 losses.update({f"{k}_{i}": v for k, v in self.get_loss(loss, aux, targets, idx, num_masks).items()})
         return losses, outputs

@@ -38,16 +38,19 @@ __device__ __forceinline__ unsigned lds_addr(const void* p) {
         reinterpret_cast<uintptr_t>(p))));
 }
 
-// two transposing reads (rows base .. base+3 and base+8 .. base+11 of a row-major bf16 tile, 16 columns per 16-lane group)
-// -> the 8 k-slot elements of one A-operand fragment; EXEC must be all ones (it is: no divergence around the call)
-__device__ __forceinline__ bf16x8a tr_read_pair(unsigned addr, int second_offset_bytes) {
-    uint2 lo, hi;
-    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3\n\ts_waitcnt lgkmcnt(0)"
-                 : "=&v"(lo), "=&v"(hi)
-                 : "v"(addr), "v"(addr + second_offset_bytes)
-                 : "memory");
-    uint4 r = make_uint4(lo.x, lo.y, hi.x, hi.y);
-    return __builtin_bit_cast(bf16x8a, r);
+// Transposing reads of a row-major bf16 tile: per 16-lane group a block of 4 rows x 16 columns, delivered column-major.  One
+// fragment of the A operand (8 k-slot elements) = rows base .. base+3 and base+8 .. base+11.  EXEC must be all ones (it is: no
+// divergence around the calls).  Issue (no wait) / collect (one lgkmcnt(0) for everything issued) are separate statements so
+// that all the fragments of a 32-key block are in flight together; the destinations are tied to the wait statement.
+__device__ __forceinline__ void tr_issue(uint2& lo, uint2& hi, unsigned addr, unsigned addr2) {
+    asm volatile("ds_read_b64_tr_b16 %0, %2\n\tds_read_b64_tr_b16 %1, %3" : "=&v"(lo), "=&v"(hi) : "v"(addr), "v"(addr2) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void tr_wait(uint2 (&lo)[N], uint2 (&hi)[N]) {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);  // nothing that reads the fragments may move above the wait
+#pragma unroll
+    for (int i = 0; i < N; ++i) asm volatile("" : "+v"(lo[i]), "+v"(hi[i]));  // ... nor any compiler copy of them: redefined here
 }
 
 // DQ / DV: head channels padded to a multiple of 16 / 32 (the LDS row lengths); D: real channel count.
@@ -150,53 +153,81 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
                 sacc[kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf, qf[s], sacc[kb], 0, 0, 0);
             }
         }
-        // ---- scale, bias, key bound; running maximum
+        // ---- scale, bias, key bound; running maximum (log2 domain).  Unmasked interior tiles (no bias, all 64 keys in range)
+        //      take the short path: max on the raw scores, one fma + one exp2 per score
         const int kbase = t * ATT_KV;
+        const bool plain = BIAS == 0 && kbase + ATT_KV <= Nk;  // wave-uniform
         float mx = ATT_NEG;
+        if (plain) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int key = kbase + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
-                float sc = sacc[kb][r] * scale_log2e;
-                if (BIAS != 0) {
-                    const int q = q0 + l31;
-                    if (q < Nq && key < Nk) {
-                        const int64_t bo = b * b_sb + head * b_sh + int64_t(q) * b_sq + key;
-                        const float bv = BIAS == 1 ? static_cast<const float*>(bias)[bo] : float(static_cast<const __bf16*>(bias)[bo]);
-                        sc = bv < -1e29f ? ATT_NEG : sc + bv * 1.4426950408889634f;
+                for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[kb][r]);
+            mx *= scale_log2e;  // scale > 0
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int key = kbase + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float sc = sacc[kb][r] * scale_log2e;
+                    if (BIAS != 0) {
+                        const int q = q0 + l31;
+                        if (q < Nq && key < Nk) {
+                            const int64_t bo = b * b_sb + head * b_sh + int64_t(q) * b_sq + key;
+                            const float bv = BIAS == 1 ? static_cast<const float*>(bias)[bo] : float(static_cast<const __bf16*>(bias)[bo]);
+                            sc = bv < -1e29f ? ATT_NEG : sc + bv * 1.4426950408889634f;
+                        }
                     }
+                    if (key >= Nk) sc = ATT_NEG;
+                    sacc[kb][r] = sc;
+                    mx = fmaxf(mx, sc);
                 }
-                if (key >= Nk) sc = ATT_NEG;
-                sacc[kb][r] = sc;
-                mx = fmaxf(mx, sc);
-            }
+        }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
         const float alpha = exp2f(m_run - m_new);  // 1 when nothing changed, 0 on the first tile
         float psum = 0.f;
         bf16x8a pf[2][2];
+        if (plain) {
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+            for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-            for (int s2 = 0; s2 < 2; ++s2)
+                for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                for (int j = 0; j < 8; ++j) {
-                    const float sc = sacc[kb][8 * s2 + j];
-                    const float p = sc <= ATT_NEG ? 0.f : exp2f(sc - m_new);  // masked scores contribute nothing, also when the row is all masked
-                    psum += p;
-                    pf[kb][s2][j] = (__bf16)p;
-                }
+                    for (int j = 0; j < 8; ++j) {
+                        const float p = exp2f(fmaf(sacc[kb][8 * s2 + j], scale_log2e, -m_new));
+                        psum += p;
+                        pf[kb][s2][j] = (__bf16)p;
+                    }
+        } else {
+#pragma unroll
+            for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) {
+                        const float sc = sacc[kb][8 * s2 + j];
+                        const float p = sc <= ATT_NEG ? 0.f : exp2f(sc - m_new);  // masked scores contribute nothing, also when the row is all masked
+                        psum += p;
+                        pf[kb][s2][j] = (__bf16)p;
+                    }
+        }
         psum += __shfl_xor(psum, 32);
         l_run = l_run * alpha + psum;
         m_run = m_new;
+        if (__any(alpha != 1.f)) {  // the maximum of some row of this wave moved: rescale (wave-uniform branch)
 #pragma unroll
-        for (int tv = 0; tv < TV; ++tv)
+            for (int tv = 0; tv < TV; ++tv)
 #pragma unroll
-            for (int r = 0; r < 16; ++r) o[tv][r] *= alpha;
-        // ---- O^T += V^T P^T: A = V^T through transposing reads of the row-major V tile
+                for (int r = 0; r < 16; ++r) o[tv][r] *= alpha;
+        }
+        // ---- O^T += V^T P^T: A = V^T through transposing reads of the row-major V tile (all fragments of a 32-key block
+        //      requested together, one wait)
 #pragma unroll
-        for (int kb = 0; kb < 2; ++kb)
+        for (int kb = 0; kb < 2; ++kb) {
+            uint2 vlo[2 * TV], vhi[2 * TV];
+            const int li = lane & 15;
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2) {
                 const int krow = 32 * kb + 16 * s2 + 4 * h;  // first key row of this lane half's 4 + 4 keys
@@ -204,12 +235,19 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
                 for (int tv = 0; tv < TV; ++tv) {
                     // 16-lane group g reads the 4 x 16 block at rows krow.., columns 32 tv + 16 (g & 1); lane 4 q' + p of the
                     // group addresses row q', columns 4 p .. 4 p + 3
-                    const int li = lane & 15;
                     const unsigned addr = lds_addr(&lv[buf][krow + (li >> 2)][32 * tv + 16 * ((lane >> 4) & 1) + 4 * (li & 3)]);
-                    const bf16x8a vf = tr_read_pair(addr, 8 * VLD * 2);
-                    o[tv] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf, pf[kb][s2], o[tv], 0, 0, 0);
+                    tr_issue(vlo[s2 * TV + tv], vhi[s2 * TV + tv], addr, addr + 8 * VLD * 2);
                 }
             }
+            tr_wait(vlo, vhi);
+#pragma unroll
+            for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                for (int tv = 0; tv < TV; ++tv) {
+                    const uint4 r = make_uint4(vlo[s2 * TV + tv].x, vlo[s2 * TV + tv].y, vhi[s2 * TV + tv].x, vhi[s2 * TV + tv].y);
+                    o[tv] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8a, r), pf[kb][s2], o[tv], 0, 0, 0);
+                }
+        }
         // buffer buf ^ 1 was last read in iteration t - 1, which every wave left through the barrier below: safe to refill now
         if (t + 1 < ntiles) tile_store(buf ^ 1);
         __syncthreads();

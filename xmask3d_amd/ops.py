@@ -197,6 +197,11 @@ class CoordinateManager:
 ALGO_AUTO, ALGO_SCALAR, ALGO_MFMA, ALGO_TILES, ALGO_SPLIT = 0, 1, 2, 3, 4
 
 
+import os as _os
+
+_SPLIT_WG_TARGET = int(_os.environ.get("XM3D_SPLIT_WG_TARGET", "512"))
+
+
 def default_tiled_algo(cin=None, cout=None, K=None):
     """algo for MFMA-eligible layers that have a tiled rulebook: the split-operand bf16 kernel (algo 4) unless
     XM3D_SPCONV_ALGO=tiles selects the exact-f32 MFMA kernel (algo 3).  The 32 -> 32 k=3 layers stay on algo 3: with two
@@ -271,8 +276,14 @@ def spconv_fwd(feats, kernel, nbr, n_out, order=None, scale=None, shift=None, re
         if ksplit is None:
             ctt = lib().xm3d_spconv_split_channels(cout) if split else lib().xm3d_spconv_tile_channels(cin, cout)
             wgs = ((n_out + 255) // 256) * (cout // ctt)
-            full = 128 if split else 256  # the split kernel runs one 512-thread workgroup per CU
-            ksplit = 1 if wgs >= full else max(1, min(K, (384 if split else 768) // max(wgs, 1)))
+            if split:
+                # one 768-thread workgroup per CU, and a workgroup's time is a chain of ~2 barrier intervals per kernel offset:
+                # small grids are spread over the offsets until ~2 workgroups per CU exist (tools/prof_3d.py batch: 13.3 / 12.7 / 13.9 ms
+                # for targets 128 / 512 / 768 on the 20-view bench batch)
+                target = _SPLIT_WG_TARGET
+                ksplit = 1 if wgs >= target else max(1, min(K, -(-target // max(wgs, 1))))
+            else:
+                ksplit = 1 if wgs >= 256 else max(1, min(K, 768 // max(wgs, 1)))
         slab = torch.empty((ksplit, n_out, cout), dtype=torch.float32, device=feats.device) if ksplit > 1 else None
         fn = lib().xm3d_spconv_fwd_split if split else lib().xm3d_spconv_fwd_tiles
         check(fn(_ptr(feats), feats.shape[0], cin, _ptr(w), K, cout, _ptr(tsrc), _ptr(tdst), _ptr(tcnt),
@@ -438,6 +449,22 @@ def geglu(x):
     out = torch.empty((*x.shape[:-1], D), dtype=x.dtype, device=x.device)
     check(lib().xm3d_geglu(_ptr(x), 0 if x.dtype == torch.float32 else 1, x.numel() // (2 * D), D, _ptr(out), _stream()), "xm3d_geglu")
     return out
+
+
+# ---------------------------------------------------------------- batched assignment
+def linear_sum_assignment(cost, n_targets):
+    """cost (M, Q, Tmax) f32 device, n_targets (M,) i32 device -> (query idx, target idx) (M, Tmax) i64, pairs sorted by query
+    index in the first n_targets[m] slots, -1 elsewhere.  One launch, no host synchronisation."""
+    _req(cost, torch.float32, "cost", 3)
+    _req(n_targets, torch.int32, "n_targets", 1)
+    M, Q, Tm = cost.shape
+    if n_targets.numel() != M:
+        raise RuntimeError("linear_sum_assignment: one target count per matrix expected")
+    oq = torch.full((M, Tm), -1, dtype=torch.int64, device=cost.device)
+    ot = torch.full((M, Tm), -1, dtype=torch.int64, device=cost.device)
+    check(lib().xm3d_linear_sum_assignment(_ptr(cost), M, Q, Tm, _ptr(n_targets), _ptr(oq), _ptr(ot), _stream()),
+          "xm3d_linear_sum_assignment")
+    return oq, ot
 
 
 # ---------------------------------------------------------------- fused softmax attention
