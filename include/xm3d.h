@@ -128,6 +128,13 @@ int xm3d_spconv_fwd_tiles(const float* in, int64_t n_in, int32_t cin, const floa
  * summation order fixed -> bitwise reproducible).  Wq = xm3d_spconv_pack_weight_split(W): K*cin*cout*4 bytes (bf16 hi and
  * lo parts in MFMA-fragment order).  Cin, Cout multiples of 32.  xm3d_spconv_split_channels(cout) = output channels one
  * workgroup owns (96 / 64 / 32): callers size the split-K factor from the resulting workgroup count. */
+/* xm3d_spconv_fwd_split2: the same with the activations ALSO kept pre-split between layers: in_split (NULL or (2, n_in, cin)
+ * bf16 = hi plane then lo plane of `in`, as written by a previous call) spares the gather path the conversion; out_split
+ * (NULL or (2, n_out, cout) bf16) receives the split copy of `out` from the epilogue.  `in` (f32) is still required. */
+int xm3d_spconv_fwd_split2(const float* in, const void* in_split, int64_t n_in, int32_t cin, const void* Wq, int32_t K,
+                           int32_t cout, const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order,
+                           int64_t n_out, const float* scale, const float* shift, const float* residual, int32_t relu,
+                           float* out, void* out_split, int32_t ksplit, float* slab, void* stream);
 int xm3d_spconv_pack_weight_split(const float* W, int32_t K, int32_t cin, int32_t cout, void* Wq, void* stream);
 int xm3d_spconv_split_channels(int32_t cout);
 int xm3d_spconv_fwd_split(const float* in, int64_t n_in, int32_t cin, const void* Wq, int32_t K, int32_t cout,

@@ -81,6 +81,31 @@ def test_split_kernel_every_instantiation(dev, cin, cout):
             assert torch.equal(out, again)
 
 
+def test_presplit_activations_chain(dev):
+    """algo 4 with activations kept pre-split between layers: conv1 emits the bf16 hi / lo copy of its output, conv2 consumes
+    it (producers then only move fragments); same result as the on-the-fly split, the copy reconstructs the f32 output to
+    2^-16, and both split-K and direct epilogues write it"""
+    from xmask3d_amd import ops
+
+    torch.manual_seed(5)
+    c = _coords(4000, 17, hi=24)
+    N = len(c)
+    cm = ops.CoordinateManager(torch.from_numpy(c).to(dev))
+    nbr, tiles, order = cm.kernel_map(1, 1, 3), cm.tiles(1, 1, 3), cm.order(1)
+    f = torch.randn(N, 64).to(dev)
+    W1, W2 = (torch.randn(27, 64, 96) * 0.05).to(dev), (torch.randn(27, 96, 64) * 0.05).to(dev)
+    for ksplit in (1, 4):
+        y1, y1s = ops.spconv_fwd(f, W1, nbr, N, order=order, tiles=tiles, relu=True, algo=ops.ALGO_SPLIT, ksplit=ksplit, want_split=True)
+        assert y1s.shape == (2, N, 96) and y1s.dtype == torch.bfloat16
+        rec = y1s[0].float() + y1s[1].float()
+        assert _rel(rec.cpu(), y1.cpu()) < 2e-5
+        a = ops.spconv_fwd(y1, W2, nbr, N, order=order, tiles=tiles, algo=ops.ALGO_SPLIT, ksplit=ksplit)                     # split on the fly
+        b = ops.spconv_fwd(y1, W2, nbr, N, order=order, tiles=tiles, algo=ops.ALGO_SPLIT, ksplit=ksplit, feats_split=y1s)    # pre-split
+        ref = so.spconv(y1.cpu().double(), W2.cpu().double(), nbr.cpu().numpy()).float()
+        assert _rel(a.cpu(), ref) < 2e-5 and _rel(b.cpu(), ref) < 2e-5
+        assert _rel(b.cpu(), a.cpu()) < 1e-5
+
+
 def test_roofline_shape_s1_full_96_to_96(dev):
     """the layer bench.py's `roofline` object is measured on (S1-full, 107 k voxels, 96 -> 96, k = 3, 418 k pairs): both
     tiled kernels against the oracle's per-offset gather-matmul-scatter in f64"""

@@ -23,7 +23,8 @@ g = torch.Generator().manual_seed(1)
 feats = torch.randn(n, cin, generator=g).to(dev)
 W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev)
 p4 = ops.pack_weight_split(W)
-run = lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=p4, tiles=tiles, relu=True, algo=ops.ALGO_SPLIT)
+fs = torch.stack([feats.bfloat16(), (feats - feats.bfloat16().float()).bfloat16()]).contiguous() if os.environ.get("PRESPLIT") else None
+run = lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=p4, tiles=tiles, relu=True, algo=ops.ALGO_SPLIT, feats_split=fs, ksplit=1)
 for _ in range(3):
     run()
 torch.cuda.synchronize()

@@ -86,6 +86,22 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, siz
 
 // out = epi(sum_z slab[z]) in fixed z order (spconv.hip; shared by the split-K paths of both sparse-conv kernels)
 int launch_slab_reduce(const float* slab, int ksplit, int64_t n_out, int cout, const float* scale, const float* shift,
-                       const float* residual, int relu, float* out, hipStream_t s);
+                       const float* residual, int relu, float* out, hipStream_t s, void* out_hi = nullptr, void* out_lo = nullptr);
+
+// f32 x 4 -> bf16 hi / lo parts (x = hi + lo up to 2^-17 |x|), 8-byte stores: the pre-split activation format of the
+// split-operand sparse conv (spconv_split.hip)
+#ifdef __HIPCC__
+__device__ __forceinline__ void store_split4(__bf16* hi, __bf16* lo, const float __attribute__((ext_vector_type(4))) v) {
+    typedef __bf16 bf16x4s __attribute__((ext_vector_type(4)));
+    bf16x4s h, l;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        h[i] = (__bf16)v[i];
+        l[i] = (__bf16)(v[i] - (float)h[i]);
+    }
+    *reinterpret_cast<bf16x4s*>(hi) = h;
+    *reinterpret_cast<bf16x4s*>(lo) = l;
+}
+#endif
 
 }  // namespace xm3d

@@ -410,7 +410,8 @@ __global__ __launch_bounds__(256, (NTT <= 2 ? 2 : 1)) void k_spconv_tiles(const 
 // out = epi(sum_z slab[z]) in fixed z order (bitwise reproducible)
 __global__ void k_slab_reduce(const float* __restrict__ slab, int ksplit, int64_t n4, int64_t stride4, int c,
                               const float* __restrict__ scale, const float* __restrict__ shift,
-                              const float* __restrict__ residual, int relu, float* __restrict__ out) {
+                              const float* __restrict__ residual, int relu, float* __restrict__ out,
+                              __bf16* __restrict__ out_hi, __bf16* __restrict__ out_lo) {
     const int64_t gs = int64_t(gridDim.x) * blockDim.x;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n4; e += gs) {
         f32x4 v = reinterpret_cast<const f32x4*>(slab)[e];
@@ -426,16 +427,18 @@ __global__ void k_slab_reduce(const float* __restrict__ slab, int ksplit, int64_
             v[3] = fmaxf(v[3], 0.f);
         }
         reinterpret_cast<f32x4*>(out)[e] = v;
+        if (out_hi) store_split4(out_hi + e * 4, out_lo + e * 4, v);
     }
 }
 
 // host-side launcher shared with spconv_split.hip
 int launch_slab_reduce(const float* slab, int ksplit, int64_t n_out, int cout, const float* scale, const float* shift,
-                       const float* residual, int relu, float* out, hipStream_t s) {
+                       const float* residual, int relu, float* out, hipStream_t s, void* out_hi, void* out_lo) {
     const int64_t n4 = n_out * cout / 4;
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
-    hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out);
+    hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out,
+                       static_cast<__bf16*>(out_hi), static_cast<__bf16*>(out_lo));
     return 0;
 }
 
@@ -642,7 +645,8 @@ extern "C" int xm3d_spconv_fwd_tiles(const float* in, int64_t n_in, int32_t cin,
             const int64_t n4 = n_out * cout / 4;
             int64_t blocks = (n4 + 255) / 256;
             if (blocks > 2048) blocks = 2048;
-            hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out);
+            hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out,
+                               static_cast<__bf16*>(nullptr), static_cast<__bf16*>(nullptr));
         }
         XM3D_LAUNCH_CHECK();
         return XM3D_OK;
@@ -660,7 +664,8 @@ extern "C" int xm3d_spconv_fwd_tiles(const float* in, int64_t n_in, int32_t cin,
         const int64_t n4 = n_out * cout / 4;
         int64_t blocks = (n4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
-        hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out);
+        hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out,
+                               static_cast<__bf16*>(nullptr), static_cast<__bf16*>(nullptr));
     }
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;

@@ -54,8 +54,8 @@ __device__ long long g_stamps[STAMP_WGS * STAMP_WAVES * STAMP_SLOTS];
 
 // ------------------------------------------------------------------ weight packing (split to bf16 hi / lo)
 // Wq as uint4[(((k * (cin/32) + sg) * (cout/16) + ng) * 2 + h) * 64 + lane] = 8 bf16: element j of lane (n16 = lane & 15,
-// q = lane >> 4) is the hi (h = 0) / lo (h = 1) part of W[k][32 sg + 16 (j >> 2) + 4 q + (j & 3)][16 ng + n16]
-// (the k-slot permutation is shared with the producers' gather so that a lane reads two 16-byte row segments).
+// q = lane >> 4) is the hi (h = 0) / lo (h = 1) part of W[k][32 sg + 8 q + j][16 ng + n16] (k-slot (q, j) = channel 8 q + j of
+// the 32-channel step, the same order in which the producers fetch a row: 8 consecutive channels per lane).
 __global__ void k_pack_weight_split(const float* __restrict__ W, int K, int cin, int cout, __bf16* __restrict__ Wq) {
     const int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // one thread per (block, h = both, lane, j)
     const int64_t total = int64_t(K) * cin * cout;
@@ -67,7 +67,7 @@ __global__ void k_pack_weight_split(const float* __restrict__ W, int K, int cin,
     const int ng = int(blk % NG);
     const int sg = int((blk / NG) % SG);
     const int k = int(blk / (int64_t(NG) * SG));
-    const int ci = 32 * sg + 16 * (j >> 2) + 4 * (lane >> 4) + (j & 3);
+    const int ci = 32 * sg + 8 * (lane >> 4) + j;
     const int co = 16 * ng + (lane & 15);
     const float w = W[(int64_t(k) * cin + ci) * cout + co];
     const __bf16 hi = (__bf16)w;
@@ -109,9 +109,12 @@ __device__ __forceinline__ void load_frag(uint4& dst, const uint4* sbase, unsign
 // item, IPC = items per chunk (= barrier interval), NG x NPW producer waves (NG staggered groups of NPW waves).
 // A CHUNK is up to IPC 16-pair items of ONE (offset, channel chunk) group: all its pairs have distinct output rows (one
 // offset), so the accumulator updates inside a chunk are independent, and its weights are one fragment set.
-template <int NT, int NTW, int CC, int IPC, int NG, int NPW>
+// PRE: the input also exists pre-split (in_hi / in_lo bf16 planes, written by the epilogue of the conv that produced it): the
+// producers then only move fragments (two 16-byte loads + two LDS stores per 32-channel step instead of 24 conversion VALU ops).
+template <int NT, int NTW, int CC, int IPC, int NG, int NPW, bool PRE>
 __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
-    const float* __restrict__ in, int cin, const uint4* __restrict__ Wq, int K, int cout, const int32_t* __restrict__ tsrc,
+    const float* __restrict__ in, const __bf16* __restrict__ in_hi, const __bf16* __restrict__ in_lo, __bf16* __restrict__ out_hi,
+    __bf16* __restrict__ out_lo, int cin, const uint4* __restrict__ Wq, int K, int cout, const int32_t* __restrict__ tsrc,
     const uint8_t* __restrict__ tdst, const int32_t* __restrict__ tcnt, const int32_t* __restrict__ order, int64_t n_out,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ residual, int relu,
     float* __restrict__ out, int ksplit, float* __restrict__ slab, int ntiles) {
@@ -233,11 +236,16 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
 #pragma unroll
             for (int u = 0; u < IPP; ++u) {
                 // padding slots read row 0 (valid memory); their MFMA columns are never accumulated (dst = -1)
-                const float* src = in + int64_t(a_ok[u] ? a_src[u] : 0) * cin + a_c * CC + 4 * q;
+                const int64_t eo = int64_t(a_ok[u] ? a_src[u] : 0) * cin + a_c * CC + 8 * q;  // this lane's 8 channels per step
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    rows[u][2 * s] = *reinterpret_cast<const f32x4*>(src + 32 * s);
-                    rows[u][2 * s + 1] = *reinterpret_cast<const f32x4*>(src + 32 * s + 16);
+                    if constexpr (PRE) {  // ready-made bf16 hi / lo fragments
+                        rows[u][2 * s] = *reinterpret_cast<const f32x4*>(in_hi + eo + 32 * s);
+                        rows[u][2 * s + 1] = *reinterpret_cast<const f32x4*>(in_lo + eo + 32 * s);
+                    } else {
+                        rows[u][2 * s] = *reinterpret_cast<const f32x4*>(in + eo + 32 * s);
+                        rows[u][2 * s + 1] = *reinterpret_cast<const f32x4*>(in + eo + 32 * s + 4);
+                    }
                 }
             }
         };
@@ -247,15 +255,20 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
                 const int e = m * IPP + u;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    bf16x8 hi, lo;
+                    if constexpr (PRE) {
+                        lds.stage[slot][e][s][0][lane] = __builtin_bit_cast(uint4, rows[u][2 * s]);
+                        lds.stage[slot][e][s][1][lane] = __builtin_bit_cast(uint4, rows[u][2 * s + 1]);
+                    } else {
+                        bf16x8 hi, lo;
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float x = rows[u][2 * s + (j >> 2)][j & 3];
-                        hi[j] = (__bf16)x;
-                        lo[j] = (__bf16)(x - (float)hi[j]);
+                        for (int j = 0; j < 8; ++j) {
+                            const float x = rows[u][2 * s + (j >> 2)][j & 3];
+                            hi[j] = (__bf16)x;
+                            lo[j] = (__bf16)(x - (float)hi[j]);
+                        }
+                        lds.stage[slot][e][s][0][lane] = __builtin_bit_cast(uint4, hi);
+                        lds.stage[slot][e][s][1][lane] = __builtin_bit_cast(uint4, lo);
                     }
-                    lds.stage[slot][e][s][0][lane] = __builtin_bit_cast(uint4, hi);
-                    lds.stage[slot][e][s][1][lane] = __builtin_bit_cast(uint4, lo);
                 }
                 if (q == 0) lds.dst[slot][e][p16] = a_ok[u] ? a_dst[u] : -1;
             }
@@ -424,6 +437,7 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
             v[3] = fmaxf(v[3], 0.f);
         }
         *reinterpret_cast<f32x4*>(out + grow * cout + c) = v;
+        if (out_hi) store_split4(out_hi + grow * cout + c, out_lo + grow * cout + c, v);  // pre-split copy for the next conv
     }
     XM3D_STAMP(STAMP_LAST);
 }
@@ -458,28 +472,44 @@ extern "C" int xm3d_spconv_pack_weight_split(const float* W, int32_t K, int32_t 
 // output channels per workgroup of the split kernel for a layer with `cout` channels
 extern "C" int xm3d_spconv_split_channels(int32_t cout) { return cout % 96 == 0 ? 96 : (cout % 64 == 0 ? 64 : 32); }
 
-extern "C" int xm3d_spconv_fwd_split(const float* in, int64_t n_in, int32_t cin, const void* Wq, int32_t K, int32_t cout,
-                                     const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order,
-                                     int64_t n_out, const float* scale, const float* shift, const float* residual,
-                                     int32_t relu, float* out, int32_t ksplit, float* slab, void* stream) {
+static int spconv_fwd_split_impl(const float* in, const void* in_split, int64_t n_in, int32_t cin, const void* Wq, int32_t K, int32_t cout,
+                                 const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order, int64_t n_out,
+                                 const float* scale, const float* shift, const float* residual, int32_t relu, float* out,
+                                 void* out_split, int32_t ksplit, float* slab, void* stream) {
     XM3D_REQUIRE(n_in >= 0 && n_out >= 0 && K >= 1, "spconv_fwd_split: bad sizes");
     XM3D_REQUIRE(cin % 32 == 0 && cout % 32 == 0 && cin >= 32, "spconv_fwd_split: cin=%d cout=%d must be multiples of 32", cin, cout);
     if (n_out == 0) return XM3D_OK;
     XM3D_REQUIRE(in && Wq && tsrc && tdst && tcnt && out, "spconv_fwd_split: null pointer");
     XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(Wq) |
-                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0,
+                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift) |
+                   reinterpret_cast<uintptr_t>(in_split) | reinterpret_cast<uintptr_t>(out_split)) & 15) == 0,
                  "spconv_fwd_split: tensors must be 16-byte aligned");
     XM3D_REQUIRE(ksplit >= 1 && ksplit <= K && (ksplit == 1 || slab), "spconv_fwd_split: ksplit=%d needs 1..K and a slab", ksplit);
     XM3D_REQUIRE(K <= 128, "spconv_fwd_split: K=%d > 128", K);
+    XM3D_REQUIRE((!in_split || (n_in * int64_t(cin)) % 8 == 0) && (!out_split || (n_out * int64_t(cout)) % 8 == 0),
+                 "spconv_fwd_split: split planes must keep 16-byte alignment (rows x channels a multiple of 8)");
     hipStream_t s = as_stream(stream);
     const int ntiles = int((n_out + SROWS - 1) / SROWS);
     const int ctt = xm3d_spconv_split_channels(cout);
     const int cc = (cin % 64 == 0) ? 64 : (cin % 96 == 0 ? 96 : 32);
     dim3 grid(ntiles, cout / ctt, ksplit);
     const uint4* wq = static_cast<const uint4*>(Wq);
-#define XM3D_SPLIT(NT, NTW, CC, IPC, NG, NPW)                                                                                         \
-    hipLaunchKernelGGL((k_spconv_split<NT, NTW, CC, IPC, NG, NPW>), grid, dim3(64 * (NT / NTW + NG * NPW)), 0, s, in, cin, wq, K, cout, \
-                       tsrc, tdst, tcnt, order, n_out, scale, shift, residual, relu, out, ksplit, slab, ntiles)
+    // split planes: (2, N, C) bf16 = hi plane followed by lo plane
+    const __bf16* in_hi = static_cast<const __bf16*>(in_split);
+    const __bf16* in_lo = in_hi ? in_hi + n_in * int64_t(cin) : nullptr;
+    __bf16* o_hi = static_cast<__bf16*>(out_split);
+    __bf16* o_lo = o_hi ? o_hi + n_out * int64_t(cout) : nullptr;
+    __bf16* k_hi = ksplit > 1 ? nullptr : o_hi;  // with split-K the reducer writes the split copy
+    __bf16* k_lo = ksplit > 1 ? nullptr : o_lo;
+#define XM3D_SPLIT_P(NT, NTW, CC, IPC, NG, NPW, PRE)                                                                                    \
+    hipLaunchKernelGGL((k_spconv_split<NT, NTW, CC, IPC, NG, NPW, PRE>), grid, dim3(64 * (NT / NTW + NG * NPW)), 0, s, in, in_hi, in_lo, \
+                       k_hi, k_lo, cin, wq, K, cout, tsrc, tdst, tcnt, order, n_out, scale, shift, residual, relu, out, ksplit, slab,    \
+                       ntiles)
+#define XM3D_SPLIT(NT, NTW, CC, IPC, NG, NPW)                     \
+    do {                                                          \
+        if (in_hi) XM3D_SPLIT_P(NT, NTW, CC, IPC, NG, NPW, true); \
+        else XM3D_SPLIT_P(NT, NTW, CC, IPC, NG, NPW, false);      \
+    } while (0)
     // (NT, CC) -> items per interval sized so that accumulator + two ring slots fit the 160 KiB LDS
     // wave split per shape (tools/spconv_bench.py, tools/spconv_stamps.py): one 16-channel tile per consumer wave, three
     // staggered groups of two producer waves; XM3D_SPLIT_VARIANT=2 selects two tiles per consumer (experiments)
@@ -503,7 +533,24 @@ extern "C" int xm3d_spconv_fwd_split(const float* in, int64_t n_in, int32_t cin,
         else XM3D_SPLIT(2, 1, 32, 8, 3, 1);
     }
 #undef XM3D_SPLIT
-    if (ksplit > 1) launch_slab_reduce(slab, ksplit, n_out, cout, scale, shift, residual, relu, out, s);
+#undef XM3D_SPLIT_P
+    if (ksplit > 1) launch_slab_reduce(slab, ksplit, n_out, cout, scale, shift, residual, relu, out, s, o_hi, o_lo);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
+}
+
+extern "C" int xm3d_spconv_fwd_split(const float* in, int64_t n_in, int32_t cin, const void* Wq, int32_t K, int32_t cout,
+                                     const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order,
+                                     int64_t n_out, const float* scale, const float* shift, const float* residual,
+                                     int32_t relu, float* out, int32_t ksplit, float* slab, void* stream) {
+    return spconv_fwd_split_impl(in, nullptr, n_in, cin, Wq, K, cout, tsrc, tdst, tcnt, order, n_out, scale, shift, residual, relu, out,
+                                 nullptr, ksplit, slab, stream);
+}
+
+extern "C" int xm3d_spconv_fwd_split2(const float* in, const void* in_split, int64_t n_in, int32_t cin, const void* Wq, int32_t K,
+                                      int32_t cout, const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order,
+                                      int64_t n_out, const float* scale, const float* shift, const float* residual, int32_t relu,
+                                      float* out, void* out_split, int32_t ksplit, float* slab, void* stream) {
+    return spconv_fwd_split_impl(in, in_split, n_in, cin, Wq, K, cout, tsrc, tdst, tcnt, order, n_out, scale, shift, residual, relu, out,
+                                 out_split, ksplit, slab, stream);
 }

@@ -122,9 +122,10 @@ class _BatchNormFn(torch.autograd.Function):
 
 # ----------------------------------------------------------------------------- tensors
 class _PendingConv:
-    def __init__(self, feats, kernel3, packed, nbr, order, n_out, tiles=None):
+    def __init__(self, feats, kernel3, packed, nbr, order, n_out, tiles=None, feats_split=None, emit_split=False):
         self.feats, self.kernel3, self.packed = feats, kernel3, packed
         self.nbr, self.order, self.n_out, self.tiles = nbr, order, n_out, tiles
+        self.feats_split, self.emit_split = feats_split, emit_split
         self.scale = self.shift = self.residual = None
         self.relu = False
 
@@ -132,9 +133,11 @@ class _PendingConv:
         return self.residual is None and not self.relu
 
     def run(self):
-        return ops.spconv_fwd(self.feats, self.kernel3, self.nbr, self.n_out, order=self.order, scale=self.scale,
-                              shift=self.shift, residual=self.residual, relu=self.relu, packed=self.packed,
-                              tiles=self.tiles)
+        """-> (features, pre-split bf16 copy or None)"""
+        r = ops.spconv_fwd(self.feats, self.kernel3, self.nbr, self.n_out, order=self.order, scale=self.scale, shift=self.shift,
+                           residual=self.residual, relu=self.relu, packed=self.packed, tiles=self.tiles,
+                           feats_split=self.feats_split, want_split=self.emit_split)
+        return r if self.emit_split else (r, None)
 
 
 class _PendingAffine:
@@ -147,7 +150,7 @@ class _PendingAffine:
         return False
 
     def run(self):
-        return ops.affine_act(self.x, self.scale, self.shift, self.residual, self.relu)
+        return ops.affine_act(self.x, self.scale, self.shift, self.residual, self.relu), None
 
 
 class SparseTensor:
@@ -164,6 +167,7 @@ class SparseTensor:
         self.coordinate_manager = coordinate_manager
         self.tensor_stride = tensor_stride
         self._F = None
+        self._Fs = None  # (2, N, C) bf16 hi / lo copy of _F, written by the split-operand conv that produced it (eval path)
         self._pending = _pending
         if features is not None:
             if features.dtype != torch.float32:
@@ -176,7 +180,7 @@ class SparseTensor:
     @property
     def F(self):
         if self._F is None:
-            self._F = self._pending.run()
+            self._F, self._Fs = self._pending.run()
             self._pending = None
         return self._F
 
@@ -233,7 +237,10 @@ def cat(*tensors):
     for t in tensors[1:]:
         if t.coordinate_manager is not t0.coordinate_manager or t.tensor_stride != t0.tensor_stride:
             raise RuntimeError("ME.cat needs tensors on the same coordinate map")
-    return t0._like(torch.cat([t.F for t in tensors], dim=1))
+    out = t0._like(torch.cat([t.F for t in tensors], dim=1))
+    if all(t._Fs is not None for t in tensors):  # keep the pre-split copies: hi and lo planes concatenated channel-wise
+        out._Fs = torch.cat([t._Fs for t in tensors], dim=2)
+    return out
 
 
 # ----------------------------------------------------------------------------- modules
@@ -309,7 +316,9 @@ class _ConvBase(nn.Module):
             tiles = cm.tiles(ts_in, ts_out, self.kernel_size, self.transposed)
         if not (self.kernel_volume == 1 and self.stride == 1):
             nbr = cm.kernel_map(ts_in, ts_out, self.kernel_size, self.transposed)
-        pend = _PendingConv(feats, k3, packed, nbr, cm.order(ts_out), n_out, tiles)
+        split = packed is not None and ops.default_tiled_algo(self.in_channels, self.out_channels, self.kernel_volume) == ops.ALGO_SPLIT
+        pend = _PendingConv(feats, k3, packed, nbr, cm.order(ts_out), n_out, tiles, feats_split=x._Fs if split else None,
+                            emit_split=split and getattr(self, "emit_split", True))
         if self.bias is not None:
             pend.shift = self.bias.detach().reshape(-1).contiguous()
         return SparseTensor(tensor_stride=ts_out, coordinate_manager=cm, _pending=pend)

@@ -57,6 +57,7 @@ class MinkUNet(nn.Module):
             stage, width = self._stage(p + skips.pop(), p, layers[4 + lvl])
             setattr(self, sname, stage)
         self.final = ME.MinkowskiConvolution(planes[7], out_channels, kernel_size=1, dimension=D)
+        self.final.emit_split = False  # consumed by dense linear heads, not by another sparse conv: no pre-split copy
         self.relu = ME.MinkowskiReLU(inplace=True)
         self.weight_initialization()
 

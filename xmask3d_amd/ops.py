@@ -238,9 +238,11 @@ def mfma_eligible(cin, cout):
 
 
 def spconv_fwd(feats, kernel, nbr, n_out, order=None, scale=None, shift=None, residual=None, relu=False,
-               algo=ALGO_AUTO, packed=None, tiles=None, ksplit=None):
+               algo=ALGO_AUTO, packed=None, tiles=None, ksplit=None, feats_split=None, want_split=False):
     """out (n_out, Cout) = epi(sum_k feats[nbr[k]] @ kernel[k]).  `packed` = pack_weight(kernel) cache;
-    `tiles` = CoordinateManager.tiles(...) selects the tiled-rulebook MFMA kernel (algo 3)."""
+    `tiles` = CoordinateManager.tiles(...) selects the tiled-rulebook MFMA kernels (algo 3 / 4).
+    algo 4 only: feats_split = the (2, n_in, Cin) bf16 hi/lo copy of feats a previous call returned; want_split=True returns
+    (out, out_split) with the (2, n_out, Cout) bf16 copy of out for the next conv (None when another algo ran)."""
     _req(feats, torch.float32, "features", 2)
     _req(kernel, torch.float32, "kernel", 3)
     K, cin, cout = kernel.shape
@@ -280,20 +282,30 @@ def spconv_fwd(feats, kernel, nbr, n_out, order=None, scale=None, shift=None, re
                 # one 768-thread workgroup per CU, and a workgroup's time is a chain of ~2 barrier intervals per kernel offset:
                 # small grids are spread over the offsets until ~2 workgroups per CU exist (tools/prof_3d.py batch: 13.3 / 12.7 / 13.9 ms
                 # for targets 128 / 512 / 768 on the 20-view bench batch)
+                # (grids that already give every CU a workgroup are left alone: split-K costs the slab round trip)
                 target = _SPLIT_WG_TARGET
-                ksplit = 1 if wgs >= target else max(1, min(K, -(-target // max(wgs, 1))))
+                ksplit = 1 if wgs >= 256 else max(1, min(K, -(-target // max(wgs, 1))))
             else:
                 ksplit = 1 if wgs >= 256 else max(1, min(K, 768 // max(wgs, 1)))
         slab = torch.empty((ksplit, n_out, cout), dtype=torch.float32, device=feats.device) if ksplit > 1 else None
-        fn = lib().xm3d_spconv_fwd_split if split else lib().xm3d_spconv_fwd_tiles
-        check(fn(_ptr(feats), feats.shape[0], cin, _ptr(w), K, cout, _ptr(tsrc), _ptr(tdst), _ptr(tcnt),
-                 _ptr(order), n_out, _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)),
-                 _ptr(out), ksplit, _ptr(slab), _stream()), "xm3d_spconv_fwd_split" if split else "xm3d_spconv_fwd_tiles")
-        return out
+        if split:
+            if feats_split is not None:
+                _req(feats_split, torch.bfloat16, "feats_split", 3)
+                if tuple(feats_split.shape) != (2, feats.shape[0], cin):
+                    raise RuntimeError(f"feats_split shape {tuple(feats_split.shape)} != (2, {feats.shape[0]}, {cin})")
+            out_split = torch.empty((2, n_out, cout), dtype=torch.bfloat16, device=feats.device) if want_split else None
+            check(lib().xm3d_spconv_fwd_split2(_ptr(feats), _ptr(feats_split), feats.shape[0], cin, _ptr(w), K, cout, _ptr(tsrc), _ptr(tdst),
+                                               _ptr(tcnt), _ptr(order), n_out, _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)),
+                                               _ptr(out), _ptr(out_split), ksplit, _ptr(slab), _stream()), "xm3d_spconv_fwd_split2")
+            return (out, out_split) if want_split else out
+        check(lib().xm3d_spconv_fwd_tiles(_ptr(feats), feats.shape[0], cin, _ptr(w), K, cout, _ptr(tsrc), _ptr(tdst), _ptr(tcnt),
+                                          _ptr(order), n_out, _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)),
+                                          _ptr(out), ksplit, _ptr(slab), _stream()), "xm3d_spconv_fwd_tiles")
+        return (out, None) if want_split else out
     check(lib().xm3d_spconv_fwd(_ptr(feats), feats.shape[0], cin, _ptr(w), K, cout, _ptr(nbr), _ptr(order), n_out,
                                 _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out), algo, _stream()),
           "xm3d_spconv_fwd")
-    return out
+    return (out, None) if want_split else out
 
 
 def spconv_bwd_weight(feats, gout, nbr, K):
