@@ -31,7 +31,7 @@ FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
 BF16_MFMA_PEAK_TF = 2500.0  # dense bf16
 HBM_PEAK_GBPS = 8000.0      # HBM3E spec (6.3 TB/s measured copy)
 L2_PEAK_GBPS = 34500.0      # aggregate L2 rate (MI355X_MICROARCH.md, L2 section)
-SPCONV_PMC_TRAFFIC_BYTES = None  # filled from profiles/r02_roofline_spconv_pmc.txt once collected
+SPCONV_PMC_TRAFFIC_BYTES = 153.0e6  # profiles/r02_roofline_spconv_pmc.txt: 2 x FETCH_SIZE (gfx950 read correction) 70.8 MB + WRITE_SIZE 82.2 MB
 DENSE_TFLOP_PER_VIEW_MIN = 2.83  # SURVEY.md §8d, dead compute pruned
 DENSE_TFLOP_PER_VIEW_REF = 4.79  # as the reference computes
 
