@@ -282,6 +282,16 @@ int xm3d_linear_sum_assignment(const float* cost, int64_t n_mat, int32_t Q, int3
                                int64_t* out_q, int64_t* out_t, void* stream);
 
 /* ---------------------------------------------------------------------------
+ * Point cloud -> pixel mapping (replaces PointCloudToImageMapper.compute_mapping, models/utils/fusion_util.py:46-142, run per
+ * view by the reference's data loaders): pts (n,3) f64 DEVICE; world_to_camera 4x4 and intrinsic 4x4 row-major f64 on the HOST
+ * (the inverse of the pose is taken by the caller, like np.linalg.inv); image (width, height), cut_bound; depth NULL or a
+ * (depth_h, depth_w) f64 DEVICE map with vis_thres.  mapping (n,3) i32 = [row, col, 1] of visible points, [0,0,0] otherwise.
+ * ------------------------------------------------------------------------- */
+int xm3d_compute_mapping(const double* pts, int64_t n, const double* world_to_camera, const double* intrinsic4,
+                         int32_t width, int32_t height, int32_t cut_bound, const double* depth, int32_t depth_h,
+                         int32_t depth_w, double vis_thres, int32_t* mapping, void* stream);
+
+/* ---------------------------------------------------------------------------
  * Exact 1-nearest-neighbour index (replaces sklearn.neighbors.KDTree(...).query(k=1) in run/infer.py:523-553,
  * :682-694): query (n,3) f32, ref (m,3) f32, out (n) i64 = arg-min squared distance, lowest index on ties.
  * ref_valid (m) u8 or NULL: reference points with 0 are ignored (if no reference point is valid the result is 0).

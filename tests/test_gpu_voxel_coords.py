@@ -108,3 +108,25 @@ def test_duplicate_and_out_of_range_coordinates_raise(dev):
     far = torch.tensor([[0, 40000, 0, 0]], dtype=torch.int32, device=dev)
     with pytest.raises(Xm3dError):
         ME.SparseTensor(torch.zeros(1, 3, device=dev), far)
+
+
+def test_compute_mapping_matches_reference_golden(dev, golden_dir):
+    """xm3d_compute_mapping against PointCloudToImageMapper.compute_mapping captured from the imported reference
+    (tests/golden/mapping.npz): with and without the depth-occlusion test, bit-exact pixel indices, and against the package's
+    own numpy restatement (synthetic.project_points) on the S1 scene's five views"""
+    import os
+
+    from xmask3d_amd import ops, synthetic
+
+    g = np.load(os.path.join(golden_dir, "mapping.npz"))
+    pts = torch.from_numpy(g["pts"]).to(dev)
+    dim = tuple(int(v) for v in g["image_dim"])
+    got = ops.compute_mapping(pts, g["pose"], g["intrinsic"], dim)
+    assert (got.cpu().numpy() == g["map_nodepth"]).all() and int(got[:, 2].sum()) > 100
+    got_d = ops.compute_mapping(pts, g["pose"], g["intrinsic"], dim, depth=torch.from_numpy(g["depth"]).to(dev))
+    assert (got_d.cpu().numpy() == g["map_depth"]).all() and 0 < int(got_d[:, 2].sum()) < int(got[:, 2].sum())
+    sc = synthetic.scene_s1()
+    P = torch.from_numpy(sc.points).to(dev)
+    for v in range(len(sc.poses)):
+        want = synthetic.project_points(sc.poses[v], sc.points)
+        assert (ops.compute_mapping(P, sc.poses[v], synthetic.scannet_intrinsics()).cpu().numpy() == want).all()

@@ -141,7 +141,9 @@ def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, lo
         model = XMASK3d(cfg).to(dev)
         if resume:
             ckpt_io.load_checkpoint(resume, model, eval=True, map_location=dev)
-    model = (model.module if hasattr(model, "module") else model).eval().set_dense_dtype(dense_dtype)
+    model = model.module if hasattr(model, "module") else model
+    restore = None if own else (model.dense_dtype, model.channels_last, model.training, model._dense_graphs is not None)
+    model.eval().set_dense_dtype(dense_dtype)
     if dense_dtype == torch.bfloat16 and dev.type == "cuda":
         model.set_channels_last(True)   # NHWC convolutions + folded GroupNorm / residual kernels
         if own:                         # a model handed in may be trained further: keep its fp32 head weights
@@ -158,22 +160,34 @@ def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, lo
     G = max(1, int(getattr(cfg, "scenes_per_forward", 4)))  # scenes whose views share one forward (pipeline.infer_scenes)
     chunks = [mine[i:i + G] for i in range(0, len(mine), G)]
 
+    vox = pipeline.default_voxelizer(cfg.voxel_size, dev)
+
     def upload(chunk):
         scs = [synthetic.scene_s1(seed=cfg.manual_seed + s) for s in chunk]
-        return scs, [pipeline.SceneOnDevice(sc, dev) for sc in scs]
+        mats = []
+        for s, sc in zip(chunk, scs):  # the augmentation draws of a scene depend on its index alone (not on grouping / prefetch order)
+            np.random.seed(cfg.manual_seed + s)
+            mats.append([vox.rigid_matrix()[0] for _ in sc.poses])
+        return scs, [pipeline.SceneOnDevice(sc, dev) for sc in scs], mats
 
     nxt = upload(chunks[0]) if chunks else None
     for ci, chunk in enumerate(chunks):
-        scs, sds = nxt
+        scs, sds, mats = nxt
         nxt = upload(chunks[ci + 1]) if ci + 1 < len(chunks) else None  # resident before this chunk's forward is issued
-        np.random.seed(cfg.manual_seed + chunk[0])
-        results = pipeline.infer_scenes(model, sds, cfg, next_scenes=None if nxt is None else nxt[1])
+        results = pipeline.infer_scenes(model, sds, cfg, vox, mats, next_scenes=None if nxt is None else nxt[1],
+                                        next_matrices=None if nxt is None else nxt[2])
         for s, scene, preds in zip(chunk, scs, results):
             gt = synthetic_labels(scene, K, s).to(dev)
             for j, p in enumerate(preds):
                 acc[j] += torch.stack(metrics.intersection_and_union(p, gt, K, tuple(cfg.test_ignore_label)))
     if world > 1:
         dist.all_reduce(acc)  # nine SUM all-reduces of the reference (infer.py:717-726) as one
+    if restore is not None:  # a borrowed model goes back the way it came (a training run continues in its own precision)
+        model.set_dense_dtype(restore[0])
+        model.set_channels_last(restore[1])
+        model.train(restore[2])
+        if not restore[3]:
+            model.enable_dense_graph(False)
     cs = cfg.category_split
     out = {n: metrics.open_vocab_scores(acc[j, 0], acc[j, 1], cs["base_category"], cs["novel_category"]) for j, n in enumerate(names)}
     if rank == 0:

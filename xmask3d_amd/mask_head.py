@@ -228,6 +228,22 @@ class SelfAttentionLayer(nn.Module):
 
     def forward(self, tgt, query_pos=None):
         q = k = tgt + query_pos
+        mha = self.self_attn
+        if tgt.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled("cuda"):
+            # bf16 inference (autocast region of XMASK3d._decode_heads): the projections nn.MultiheadAttention runs, HIP flash
+            # attention in between (xm3d_attention_fwd)
+            E, H = mha.embed_dim, mha.num_heads
+            w, b = mha.in_proj_weight, mha.in_proj_bias
+            L, B = tgt.shape[:2]
+            qk = F.linear(q, w[: 2 * E], b[: 2 * E])                       # (L, B, 2E): q and k share their input
+            v = F.linear(tgt, w[2 * E:], b[2 * E:])
+            q4 = qk[..., :E].unflatten(-1, (H, E // H)).transpose(0, 1)    # (B, L, H, d) views
+            k4 = qk[..., E:].unflatten(-1, (H, E // H)).transpose(0, 1)
+            v4 = v.view(L, B, H, E // H).transpose(0, 1)
+            if ops.attention_supported(q4, k4, v4):
+                o = torch.empty((L, B, E), dtype=q4.dtype, device=tgt.device)
+                ops.attention(q4, k4, v4, out=o.view(L, B, H, E // H).transpose(0, 1))
+                return self.norm(tgt + F.linear(o, mha.out_proj.weight, mha.out_proj.bias))
         return self.norm(tgt + self.self_attn(q, k, value=tgt, need_weights=False)[0])
 
 

@@ -350,6 +350,11 @@ class MinkowskiBatchNorm(nn.Module):
     def forward(self, x: SparseTensor) -> SparseTensor:
         bn = self.bn
         use_batch = self.training or not bn.track_running_stats
+        if not use_batch and torch.is_grad_enabled() and (x.F.requires_grad or (bn.affine and (bn.weight.requires_grad or bn.bias.requires_grad))):
+            # eval-mode statistics with gradients wanted (frozen-BN fine-tuning): the folded / detached affine below would cut
+            # the graph, so run the differentiable torch form
+            return x._like(F.batch_norm(x.F, bn.running_mean, bn.running_var, bn.weight if bn.affine else None,
+                                        bn.bias if bn.affine else None, False, 0.0, bn.eps))
         if not use_batch:
             key = (bn.running_mean._version, bn.running_var._version, bn.running_mean.data_ptr(),
                    bn.weight._version if bn.affine else 0, bn.bias._version if bn.affine else 0)

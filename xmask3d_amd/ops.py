@@ -463,6 +463,26 @@ def geglu(x):
     return out
 
 
+# ---------------------------------------------------------------- point -> pixel mapping
+def compute_mapping(points, camera_to_world, intrinsic, image_dim=(320, 240), cut_bound=10, depth=None, vis_thres=0.25):
+    """points (n,3) f64 device; camera_to_world / intrinsic 4x4 host arrays; depth None or (H,W) f64 device map
+    -> (n,3) int32 [row, col, visible] like PointCloudToImageMapper.compute_mapping (fusion_util.py:46-142)."""
+    _req(points, torch.float64, "points", 2)
+    if points.shape[1] != 3:
+        raise RuntimeError("compute_mapping: points must be (n, 3)")
+    w2c = np.ascontiguousarray(np.linalg.inv(np.asarray(camera_to_world, dtype=np.float64).reshape(4, 4)))
+    k4 = np.ascontiguousarray(np.asarray(intrinsic, dtype=np.float64).reshape(4, 4))
+    dh = dw = 0
+    if depth is not None:
+        _req(depth, torch.float64, "depth", 2)
+        dh, dw = depth.shape
+    out = torch.empty((points.shape[0], 3), dtype=torch.int32, device=points.device)
+    check(lib().xm3d_compute_mapping(_ptr(points), points.shape[0], w2c.ctypes.data_as(ctypes.c_void_p), k4.ctypes.data_as(ctypes.c_void_p),
+                                     int(image_dim[0]), int(image_dim[1]), int(cut_bound), _ptr(depth), dh, dw, float(vis_thres), _ptr(out),
+                                     _stream()), "xm3d_compute_mapping")
+    return out
+
+
 # ---------------------------------------------------------------- batched assignment
 def linear_sum_assignment(cost, n_targets):
     """cost (M, Q, Tmax) f32 device, n_targets (M,) i32 device -> (query idx, target idx) (M, Tmax) i64, pairs sorted by query
