@@ -109,10 +109,13 @@ def test_dense_graph_replay_matches_eager(dev, models):
         for v in (1, 3, 1):  # replay with different inputs, and again with the first
             _, ref = gpu(pipeline.build_view_batch(sd, v, vox, T))
             _, out = g(pipeline.build_view_batch(sd, v, vox, T))
-            assert _rel(out["pred_masks"], ref["pred_masks"]) < 2e-3  # library algorithm choice may differ warm-up vs capture
-            # mask-CLIP thresholds the masks per 14x14 patch: a 1e-5 wobble from a different library algorithm choice
-            # can flip a patch, hence the looser bound on its embedding
-            assert _rel(out["mask_embed_clip"], ref["mask_embed_clip"]) < 3e-2
+            # replay == eager up to the convolution algorithm the library picks per call (both sit 1e-5..4e-4 from the CPU oracle,
+            # tests/test_gpu_bench_parity.py: fp32_eager vs fp32_graph_nhwc)
+            assert _rel(out["pred_masks"], ref["pred_masks"]) < 1e-3
+            # mask-CLIP thresholds the masks per 14x14 patch (clip.py:272-310): a 1e-5 wobble can flip ONE patch of ONE query's
+            # attention mask - the round-1 "3e-2" was such a flip.  Bound every query but the two worst, count the flips.
+            ce = (out["mask_embed_clip"] - ref["mask_embed_clip"]).float().abs().amax(-1).flatten() / ref["mask_embed_clip"].abs().max()
+            assert ce.sort().values[:-2].max().item() < 1e-3 and int((ce > 1e-2).sum()) <= 2
             assert _rel(out["pred_3d"], ref["pred_3d"]) < 1e-6
 
 

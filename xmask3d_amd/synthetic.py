@@ -128,6 +128,7 @@ class Scene:
     poses: list = field(default_factory=list)  # camera->world 4x4 per view
     images: list = field(default_factory=list)  # (512,512,3) f32 0..255 per view
     captions: list = field(default_factory=list)
+    depths: list = field(default_factory=list)  # optional (240,320) f64 metres per view: occlusion test of the mapping
 
 
 def scene_s0(seed=5557) -> Scene:
@@ -151,6 +152,8 @@ def scene_s1(seed=5557, n_points=120000, n_views=5) -> Scene:
 
 def view_subset(scene: Scene, view: int, depth=None):
     """Visible points of one view + their pixel rows/cols (data_loader_infer.py:161-176,255-258)."""
+    if depth is None and len(scene.depths) > view:
+        depth = scene.depths[view]
     m = project_points(scene.poses[view], scene.points, depth)
     vis = m[:, 2] == 1
     rows = m[vis]
