@@ -309,6 +309,13 @@ int xm3d_nearest_index(const float* query, int64_t n, const float* ref, int64_t 
  * same segment; entries of segments without reference points, and all non-query entries, are left untouched. */
 int xm3d_nearest_index_segmented(const float* pts, const int64_t* desc, int32_t n_seg, int64_t max_queries, int64_t* out,
                                  void* stream);
+/* "Every point without a value takes the nearest point that has one" in one call (run/infer.py:682-694: labels of never-seen
+ * scene points from a KD-tree over the seen ones): xyz (n,3) f32, valid (n) u8; out[i] = i where valid, else the index of the
+ * nearest valid point - same squared-f32 distance and lowest-index tie rule as xm3d_nearest_index, identity when nothing is
+ * valid.  The valid points are binned into a 64^3 grid over their bounding box (cell edge >= `cell`) by a counting sort
+ * on the cells' Morton codes; every query descends the implied octree nearest child first; no host synchronisation.  ws: xm3d_nearest_valid_fill_workspace_bytes(n) bytes. */
+int64_t xm3d_nearest_valid_fill_workspace_bytes(int64_t n);
+int xm3d_nearest_valid_fill(const float* xyz, int64_t n, const uint8_t* valid, float cell, int64_t* out, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

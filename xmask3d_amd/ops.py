@@ -627,6 +627,22 @@ def nearest_index_segmented(pts, desc, max_queries, out):
     return out
 
 
+def nearest_valid_fill(xyz, valid, cell=0.1):
+    """xyz (n,3) f32, valid (n,) bool/uint8 -> (n,) i64: own index where valid, else the index of the nearest valid point
+    (exact, lowest index on ties, identity when nothing is valid).  Uniform-grid search, no host synchronisation."""
+    _req(xyz, torch.float32, "xyz", 2)
+    if valid.dtype == torch.bool:
+        valid = valid.to(torch.uint8)
+    _req(valid, torch.uint8, "valid", 1)
+    if xyz.shape[1] != 3 or valid.numel() != xyz.shape[0]:
+        raise RuntimeError("nearest_valid_fill: xyz (n,3) and valid (n,) expected")
+    n = xyz.shape[0]
+    out = torch.empty(n, dtype=torch.int64, device=xyz.device)
+    ws = torch.empty(lib().xm3d_nearest_valid_fill_workspace_bytes(n), dtype=torch.uint8, device=xyz.device)
+    check(lib().xm3d_nearest_valid_fill(_ptr(xyz), n, _ptr(valid), float(cell), _ptr(out), _ptr(ws), _stream()), "xm3d_nearest_valid_fill")
+    return out
+
+
 def nearest_index(query, ref, ref_valid=None, counts=None):
     """(n,3) f32, (m,3) f32 -> (n,) i64 index of the nearest reference point (exact, lowest index on ties).
     ref_valid (m,) uint8/bool: only reference points with a non-zero flag are considered.

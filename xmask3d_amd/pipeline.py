@@ -167,10 +167,16 @@ def nearest_index(query: torch.Tensor, ref: torch.Tensor, ref_valid=None):
     return ops.nearest_index(query.float().contiguous(), ref.float().contiguous(), ref_valid)
 
 
-def nearest_valid_fill(xyz: torch.Tensor, valid: torch.Tensor):
-    """For every point: its own index if `valid`, else the index of the nearest valid point.  No host synchronisation and
-    no wasted scanning: rows are ordered on the device (queries: invalid first, references: valid first) and the live
-    counts stay in device memory (xm3d_nearest_index `counts`)."""
+def nearest_valid_fill(xyz: torch.Tensor, valid: torch.Tensor, method: str = "scan"):
+    """For every point: its own index if `valid`, else the index of the nearest valid point (exact, lowest index on ties;
+    identity when nothing is valid).  No host synchronisation either way.
+    method "scan": rows are ordered on the device (queries: invalid first, references: valid first), the live counts stay in
+    device memory (xm3d_nearest_index `counts`) and every query scans every reference through LDS.
+    method "octree": one C-ABI call, xm3d_nearest_valid_fill (Morton-ordered cells, depth-first descent per query): the same
+    indices; faster when the holes are small against the cloud (few candidates per query), slower on the S1 vote fill where
+    two thirds of the room were never seen and the queries lie metres from the nearest seen point (measured)."""
+    if method == "octree":
+        return ops.nearest_valid_fill(xyz.float().contiguous(), valid)
     n = xyz.shape[0]
     xyz = xyz.float()
     q_order = torch.argsort(valid.to(torch.uint8), stable=True)          # invalid points first = the queries
