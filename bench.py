@@ -203,7 +203,7 @@ def train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log, train_dt
     log(f"training leg: {args.train_steps} iterations in {dt:.3f} s")
     return {"iters_per_s": args.train_steps / dt, "ms_per_iter": dt / args.train_steps * 1e3, "steps": args.train_steps,
             "views_per_gpu": 1, "global_batch_views": world, "frozen_nets_dtype": train_dtype,
-            "scope": "forward + 37 weighted losses (CPU Hungarian matching like the reference) + backward + AdamW; frozen UNet "
+            "scope": "forward + 37 weighted losses (Hungarian matching of all 10 decoder outputs in one HIP launch) + backward + AdamW; frozen UNet "
                      "forward/backward replayed as HIP graphs; DDP gradient all-reduce + MinkowskiSyncBatchNorm when n_gpus > 1"}
 
 
@@ -420,8 +420,8 @@ def main():
                          "library-kernel dense stage reported under roofline_dense_stage")
     roofline_stage = {"bound": "mfma", "achieved": dense_tflop / (dense_ms * 1e-3), "peak": peak, "unit": "TFLOP/s",
                       "frac": dense_tflop / (dense_ms * 1e-3) / peak, "traffic": None, "views_per_forward": vb,
-                      "scope": "dense 2D branch per view (SD VAE+UNet, projections, pixel+transformer decoder, mask-CLIP): MIOpen / hipBLASLt / "
-                               "AOTriton kernels + HIP GroupNorm, " + ("HIP graph replay" if not args.no_graph else "eager launches"),
+                      "scope": "dense 2D branch per view (SD VAE+UNet, projections, pixel+transformer decoder, mask-CLIP): MIOpen / hipBLASLt "
+                               "kernels + HIP flash attention (AOTriton only for the VAE's d=512 head) + HIP GroupNorm, " + ("HIP graph replay" if not args.no_graph else "eager launches"),
                       "ms_per_view": dense_ms, "algorithmic_tflop_per_view": dense_tflop, "sparse3d_ms_per_view": sparse_ms}
 
     cpu_baseline = None

@@ -500,10 +500,13 @@ def linear_sum_assignment(cost, n_targets):
 
 
 # ---------------------------------------------------------------- fused softmax attention
+_ATTENTION_OFF = _os.environ.get("XM3D_ATTENTION", "hip") == "library"  # A/B switch for measurements: library SDPA everywhere
+
+
 def attention_supported(q, k, v, bias=None):
     """True when xm3d_attention_fwd takes these tensors as they are (bf16 device tensors (B,N,H,D), channels contiguous, 16-byte
     rows, D a multiple of 8 up to 160, no gradient wanted); callers keep the library path for everything else"""
-    if torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad):
+    if _ATTENTION_OFF or (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)):
         return False
     for t in (q, k, v):
         if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 4 or t.stride(3) != 1 or t.data_ptr() % 16:
