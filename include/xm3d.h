@@ -309,6 +309,14 @@ int xm3d_nearest_index(const float* query, int64_t n, const float* ref, int64_t 
  * same segment; entries of segments without reference points, and all non-query entries, are left untouched. */
 int xm3d_nearest_index_segmented(const float* pts, const int64_t* desc, int32_t n_seg, int64_t max_queries, int64_t* out,
                                  void* stream);
+/* Scene votes (run/infer.py:642-661: scene_pred[mask_2d, logits_pred] += 1 per view for the fused / 2D-only / 3D-only
+ * predictions, counter[mask_2d] += 1; :690-694 torch.max(scene_pred, dim=1)) for all views of a group of scenes at once.
+ * rows (n_points) i64: table row of every visible point (scene offset + point index); pred (n_kinds, n_points) i64 class ids;
+ * votes (n_kinds, n_rows, n_cls) i32 scratch (zeroed here); label (n_kinds, n_rows) i64 <- first maximal class per row (0 for
+ * rows without votes); seen (n_rows) u8 <- row received a vote of kind 0.  Out-of-range rows / classes set the sticky device
+ * flag (xm3d_check_flag) and are skipped.  No host synchronisation. */
+int xm3d_scene_votes(const int64_t* rows, const int64_t* pred, int32_t n_kinds, int64_t n_points, int64_t n_rows, int32_t n_cls,
+                     int32_t* votes, int64_t* label, uint8_t* seen, void* stream);
 /* "Every point without a value takes the nearest point that has one" in one call (run/infer.py:682-694: labels of never-seen
  * scene points from a KD-tree over the seen ones): xyz (n,3) f32, valid (n) u8; out[i] = i where valid, else the index of the
  * nearest valid point - same squared-f32 distance and lowest-index tie rule as xm3d_nearest_index, identity when nothing is

@@ -54,11 +54,14 @@ def test_eval_forward_matches_cpu_oracle(dev, models):
               "ori_coords": torch.cat([torch.zeros(len(pts), 1), torch.from_numpy(pts).float()], 1)}
     _, ref = model_oracle.forward_cpu(cpu, cbatch)
     # (stage-by-stage bounds down to the per-point logits, for the fp32 and the bench configuration: tests/test_gpu_bench_parity.py)
-    assert _rel(out["pred_3d"], ref["pred_3d"]) < 1e-3
-    assert _rel(out["pred_masks"], ref["pred_masks"]) < 5e-3
-    assert _rel(out["mask_embed"], ref["mask_embed"]) < 5e-3
-    assert _rel(out["mask_embed_clip"], ref["mask_embed_clip"]) < 5e-3
-    assert (out["pred_logits"].cpu() - ref["pred_logits"]).abs().max().item() < 5e-2  # logit_scale*cos, scale ~14
+    # fp32 eager, batch 1 = the reference's configuration: the fp32 bounds of tests/test_gpu_bench_parity.py (measured 5e-6 /
+    # 2e-4 / 4e-4 / 2e-6 / 3e-4); mask-CLIP may flip one 14x14 patch of one query at the 0.5 threshold: all but the two worst
+    assert _rel(out["pred_3d"], ref["pred_3d"]) < 5e-5
+    assert _rel(out["pred_masks"], ref["pred_masks"]) < 1e-3
+    assert _rel(out["mask_embed"], ref["mask_embed"]) < 1e-3
+    ce = (out["mask_embed_clip"][0].float().cpu() - ref["mask_embed_clip"][0]).abs().amax(-1) / ref["mask_embed_clip"][0].abs().max()
+    assert ce.sort().values[: ce.numel() - 2].max().item() < 1e-4
+    assert (out["pred_logits"].cpu() - ref["pred_logits"]).abs().max().item() < 1e-3  # logit_scale*cos, scale ~14
     assert (out["binary_pred"].cpu() == ref["binary_pred"]).float().mean().item() > 0.999
     # fusion: where the discrete mask sets agree the fused features must agree
     m_g, m_r = out["final_mask_3d"][0].cpu(), ref["final_mask_3d"][0]

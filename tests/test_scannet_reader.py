@@ -81,8 +81,8 @@ def test_disk_scene_through_the_device_pipeline(dev, disk_scene):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     cfg = load_cfg_from_cfg_file(os.path.join(root, "configs", "xmask3d_scannet_B15N4.yaml"))
     torch.manual_seed(0)
-    model = pipeline.make_inference_model(XMASK3d(cfg).eval(), dev, torch.bfloat16)
+    model = pipeline.make_inference_model(XMASK3d(cfg).eval(), dev, torch.bfloat16, graphs=False)
     sd = pipeline.SceneOnDevice(sc, dev)
     vox = pipeline.default_voxelizer(cfg.voxel_size, dev)
-    fused, p2d, p3d = pipeline.infer_scene(model, sd, cfg, vox, [np.diag([50.0, 50.0, 50.0, 1.0])] * 3)
+    fused, p2d, p3d = pipeline.infer_scene(model, sd, cfg, vox, [np.diag([50.0, 50.0, 50.0, 1.0])] * 3, views_per_batch=1)
     assert fused.shape[0] == sc.points.shape[0] and fused.dtype == torch.long

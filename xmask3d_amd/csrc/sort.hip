@@ -89,7 +89,7 @@ extern "C" int xm3d_check_flag(void) {
     XM3D_HIP(hipMemcpy(&h, f, sizeof(int), hipMemcpyDeviceToHost));
     if (h != 0) {
         XM3D_HIP(hipMemset(f, 0, sizeof(int)));
-        xm3d::set_error(h == XM3D_ERANGE ? "coordinate outside packable range" : "hash table overflow");
+        xm3d::set_error(h == XM3D_ERANGE ? "coordinate / index outside the valid range" : "hash table overflow");
     }
     return h;
 }

@@ -630,6 +630,22 @@ def nearest_index_segmented(pts, desc, max_queries, out):
     return out
 
 
+def scene_votes(rows, pred, n_rows, n_cls):
+    """rows (Np,) i64 table row per visible point, pred (K, Np) i64 class ids -> (label (K, n_rows) i64 = first maximal class of
+    the vote table, seen (n_rows,) bool = row got a vote).  Two launches, no host synchronisation."""
+    _req(rows, torch.int64, "rows", 1)
+    _req(pred, torch.int64, "pred", 2)
+    if pred.shape[1] != rows.shape[0]:
+        raise RuntimeError("scene_votes: pred (K, Np) and rows (Np,) expected")
+    K = pred.shape[0]
+    votes = torch.empty((K, n_rows, n_cls), dtype=torch.int32, device=rows.device)
+    label = torch.empty((K, n_rows), dtype=torch.int64, device=rows.device)
+    seen = torch.empty(n_rows, dtype=torch.uint8, device=rows.device)
+    check(lib().xm3d_scene_votes(_ptr(rows), _ptr(pred), K, rows.shape[0], int(n_rows), int(n_cls), _ptr(votes), _ptr(label), _ptr(seen),
+                                 _stream()), "xm3d_scene_votes")
+    return label, seen.view(torch.bool)
+
+
 def nearest_valid_fill(xyz, valid, cell=0.1):
     """xyz (n,3) f32, valid (n,) bool/uint8 -> (n,) i64: own index where valid, else the index of the nearest valid point
     (exact, lowest index on ties, identity when nothing is valid).  Uniform-grid search, no host synchronisation."""

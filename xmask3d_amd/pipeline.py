@@ -101,9 +101,13 @@ def build_group_batch(groups, voxelizer: Voxelizer, matrices=None):
     base, b = 0, 0
     offsets = [0]
     dev = groups[0][0].device
+    vrows, row_base = [], [0]   # vote-table rows of the visible points: scene offset + point index (xm3d_scene_votes)
     for gi, (sd, views) in enumerate(groups):
         whole = list(views) == list(range(len(sd.views)))
         b0 = b
+        idx = sd.idx_all if whole else torch.cat([sd.views[v]["idx"] for v in views])
+        vrows.append(idx if row_base[-1] == 0 else idx + row_base[-1])
+        row_base.append(row_base[-1] + sd.n)
         for vi, v in enumerate(views):
             vw = sd.views[v]
             pts = sd.points[vw["idx"]].contiguous()
@@ -128,7 +132,8 @@ def build_group_batch(groups, voxelizer: Voxelizer, matrices=None):
             "x_label": xs[0] if one else torch.cat(xs), "y_label": ys[0] if one else torch.cat(ys),
             "inds_reconstruct": torch.cat(inv), "ori_coords": torch.cat(ori), "captions": tuple(caps),
             "coords": coords, "label_2d": None, "labels_3d": None, "use_pure_3d": False, "point_offsets": offsets,
-            "point_view": vids[0] if one else torch.cat(vids)}
+            "point_view": vids[0] if one else torch.cat(vids),
+            "vote_rows": vrows[0] if len(vrows) == 1 else torch.cat(vrows), "vote_row_base": row_base}
 
 
 def build_train_batch(sd: SceneOnDevice, views, voxelizer: Voxelizer, seed=0, n_classes=15, ignore=(19, 20)):
@@ -309,8 +314,12 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
     double the duration of the convolution kernels they share the device with, tools/timeline_events.py.)"""
     voxelizer = voxelizer or default_voxelizer(cfg.voxel_size, sd.device)
     ncls = len(cfg.category_split["base_category"]) + len(cfg.category_split["novel_category"])
-    votes = [torch.zeros((sd.n, ncls), dtype=torch.int32, device=sd.device) for _ in range(3 if with_ablations else 1)]
-    seen = torch.zeros(sd.n, dtype=torch.bool, device=sd.device)
+    votes = seen = labels = None
+
+    def tables():
+        return ([torch.zeros((sd.n, ncls), dtype=torch.int32, device=sd.device) for _ in range(3 if with_ablations else 1)],
+                torch.zeros(sd.n, dtype=torch.bool, device=sd.device))
+
     nv = len(sd.views)
     step = views_per_batch or nv
     staged = step >= nv and sd.device.type == "cuda" and getattr(model, "_dense_graphs", None) is not None and not model.training
@@ -332,12 +341,20 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
             _, outputs = model(batch)
         if "fused_cat" in outputs:  # batched fusion ran: post-process and vote for all views of the batch in one go
             preds = postprocess_scene(cfg, outputs, batch, with_ablations)
+            if len(views) == nv and "vote_rows" in batch:  # the whole scene in one forward: votes + labels in two launches
+                label, seen = ops.scene_votes(batch["vote_rows"], torch.stack([p for p in preds if p is not None]), sd.n, ncls)
+                labels = [label[k] for k in range(label.shape[0])]
+                continue
+            if votes is None:
+                votes, seen = tables()
             idx = sd.idx_all if len(views) == nv else torch.cat([sd.views[v]["idx"] for v in views])
             for vt, p in zip(votes, preds):
                 if p is not None:
                     vt.index_put_((idx, p), torch.ones_like(p, dtype=torch.int32), accumulate=True)
             seen.index_fill_(0, idx, True)
             continue
+        if votes is None:
+            votes, seen = tables()
         for s, v in enumerate(views):
             preds = postprocess_view(cfg, outputs, batch, with_ablations, s)
             idx = sd.views[v]["idx"]
@@ -348,7 +365,7 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
     if hasattr(model, "mark"):
         model.mark("V1")  # per-view post-processing and votes done
     fill = nearest_valid_fill(sd.points, seen)  # unseen points take the label of the nearest seen point (infer.py:682-694)
-    result = [vt.argmax(1)[fill] for vt in votes]
+    result = [lb[fill] for lb in labels] if labels is not None else [vt.argmax(1)[fill] for vt in votes]
     if hasattr(model, "mark"):
         model.mark("P1")  # end of this scene's post-processing (tools/timeline_events.py)
     if staged and next_scene is not None:
@@ -390,20 +407,13 @@ def infer_scenes(model, sds, cfg, voxelizer=None, matrices=None, with_ablations=
     outputs = model.eval_fuse(batch, front, model.eval_dense(batch, front))
     model.mark("F1")
     preds = postprocess_scene(cfg, outputs, batch, with_ablations)
-    off = batch["point_offsets"]
-    results, v0 = [], 0
-    for sd in sds:
-        lo, hi = off[v0], off[v0 + len(sd.views)]
-        v0 += len(sd.views)
-        votes = []
-        for p in preds:
-            if p is not None:
-                vt = torch.zeros((sd.n, ncls), dtype=torch.int32, device=dev)
-                pj = p[lo:hi]
-                votes.append(vt.index_put_((sd.idx_all, pj), torch.ones_like(pj, dtype=torch.int32), accumulate=True))
-        seen = torch.zeros(sd.n, dtype=torch.bool, device=dev).index_fill_(0, sd.idx_all, True)
-        fill = nearest_valid_fill(sd.points, seen)
-        results.append([vt.argmax(1)[fill] for vt in votes] + [None] * (3 - len(votes) if not with_ablations else 0))
+    # votes of all views of all scenes, first-max label per scene point and the "seen" flags: two launches (xm3d_scene_votes)
+    rb = batch["vote_row_base"]
+    label, seen = ops.scene_votes(batch["vote_rows"], torch.stack([p for p in preds if p is not None]), rb[-1], ncls)
+    results = []
+    for j, sd in enumerate(sds):
+        fill = nearest_valid_fill(sd.points, seen[rb[j]:rb[j + 1]])  # unseen points take the nearest seen point's label
+        results.append([label[k, rb[j]:rb[j + 1]][fill] for k in range(label.shape[0])] + [None] * (3 - label.shape[0]))
     model.mark("P1")
     if next_scenes is not None:
         nxt = list(next_scenes)
