@@ -324,6 +324,13 @@ int xm3d_scene_votes(const int64_t* rows, const int64_t* pred, int32_t n_kinds, 
  * on the cells' Morton codes; every query descends the implied octree nearest child first; no host synchronisation.  ws: xm3d_nearest_valid_fill_workspace_bytes(n) bytes. */
 int64_t xm3d_nearest_valid_fill_workspace_bytes(int64_t n);
 int xm3d_nearest_valid_fill(const float* xyz, int64_t n, const uint8_t* valid, float cell, int64_t* out, void* ws, void* stream);
+/* The same contract, Morton-sorted and tile-pruned (nearest_sorted.hip): queries and valid points are sorted along a Morton
+ * curve (one 31-bit radix sort), a wave of 64 neighbouring queries scans - LDS broadcast, like xm3d_nearest_index - only the
+ * 64-point reference tiles whose bounding box is not farther from the queries' box than their worst best-distance.
+ * For many queries far from the valid points (scene votes with large unseen regions).  ws: 256-byte aligned,
+ * xm3d_nearest_valid_fill_sorted_workspace_bytes(n) bytes.  No host synchronisation. */
+int64_t xm3d_nearest_valid_fill_sorted_workspace_bytes(int64_t n);
+int xm3d_nearest_valid_fill_sorted(const float* xyz, int64_t n, const uint8_t* valid, int64_t* out, void* ws, void* stream);
 
 #ifdef __cplusplus
 }

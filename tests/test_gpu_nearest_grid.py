@@ -56,6 +56,8 @@ def test_grid_fill_equals_bruteforce(dev, name):
     assert torch.equal(got, want), (name, int((got != want).sum()))
     for cell in (0.03, 0.5):  # the answer does not depend on the cell edge
         assert torch.equal(ops.nearest_valid_fill(xyz, valid, cell), want), (name, cell)
+    got = ops.nearest_valid_fill(xyz, valid, method="sorted")  # Morton-sorted, tile-pruned scan: the same indices again
+    assert torch.equal(got, want), (name, "sorted", int((got != want).sum()))
 
 
 def test_grid_fill_at_scene_size(dev):
@@ -69,6 +71,7 @@ def test_grid_fill_at_scene_size(dev):
         seen |= v["vis"]
     xyz = sd.points.float().contiguous()
     assert torch.equal(ops.nearest_valid_fill(xyz, seen), brute(xyz, seen))
+    assert torch.equal(ops.nearest_valid_fill(xyz, seen, method="sorted"), brute(xyz, seen))
 
 
 def test_grid_fill_argument_errors(dev):

@@ -19,6 +19,6 @@ g = torch.Generator(device="cpu").manual_seed(0)
 for name, valid in (("S1 vote fill (5 views seen)", seen), ("random 35% valid", (torch.rand(sd.n, generator=g) < 0.35).to(dev)),
                     ("random 90% valid", (torch.rand(sd.n, generator=g) < 0.9).to(dev))):
     a = pipeline.nearest_valid_fill(xyz, valid, "scan"); b = pipeline.nearest_valid_fill(xyz, valid, "octree")
-    assert torch.equal(a, b)
-    print(f"{name}: n={sd.n} valid={int(valid.sum())} scan {ev(lambda: pipeline.nearest_valid_fill(xyz, valid, 'scan')):.0f} us  octree {ev(lambda: pipeline.nearest_valid_fill(xyz, valid, 'octree')):.0f} us")
+    assert torch.equal(a, b) and torch.equal(a, pipeline.nearest_valid_fill(xyz, valid, 'sorted'))
+    print(f"{name}: n={sd.n} valid={int(valid.sum())} scan {ev(lambda: pipeline.nearest_valid_fill(xyz, valid, 'scan')):.0f} us  octree {ev(lambda: pipeline.nearest_valid_fill(xyz, valid, 'octree')):.0f} us  sorted {ev(lambda: pipeline.nearest_valid_fill(xyz, valid, 'sorted')):.0f} us")
 PY

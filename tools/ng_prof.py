@@ -9,5 +9,6 @@ seen = torch.zeros(sd.n, dtype=torch.bool, device=dev)
 for v in sd.views[:nv]: seen |= v["vis"]
 xyz = sd.points.float().contiguous()
 print("n", sd.n, "seen", int(seen.sum()))
-for _ in range(5): ops.nearest_valid_fill(xyz, seen)
+meth = sys.argv[2] if len(sys.argv) > 2 else "octree"
+for _ in range(5): ops.nearest_valid_fill(xyz, seen, method=meth)
 torch.cuda.synchronize()

@@ -65,6 +65,8 @@ _SIGS = {
     "xm3d_scene_votes": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_nearest_valid_fill_workspace_bytes": (ctypes.c_int64, [c_i64]),
     "xm3d_nearest_valid_fill": (ctypes.c_int, [c_vp, c_i64, c_vp, ctypes.c_float, c_vp, c_vp, c_vp]),
+    "xm3d_nearest_valid_fill_sorted_workspace_bytes": (ctypes.c_int64, [c_i64]),
+    "xm3d_nearest_valid_fill_sorted": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_msda_forward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp]),
     "xm3d_msda_backward": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp, c_vp, c_vp]),
     "xm3d_msda_forward_f64": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp] + [c_i32] * 7 + [c_vp, c_vp]),

@@ -646,17 +646,25 @@ def scene_votes(rows, pred, n_rows, n_cls):
     return label, seen.view(torch.bool)
 
 
-def nearest_valid_fill(xyz, valid, cell=0.1):
+def nearest_valid_fill(xyz, valid, cell=0.1, method="octree"):
     """xyz (n,3) f32, valid (n,) bool/uint8 -> (n,) i64: own index where valid, else the index of the nearest valid point
-    (exact, lowest index on ties, identity when nothing is valid).  Uniform-grid search, no host synchronisation."""
+    (exact, lowest index on ties, identity when nothing is valid).  No host synchronisation.
+    method "octree": Morton-ordered cells + depth-first descent per query (best for small holes);
+    method "sorted": Morton-sorted queries and references, tile-pruned LDS scan (best for many far queries)."""
     _req(xyz, torch.float32, "xyz", 2)
     if valid.dtype == torch.bool:
-        valid = valid.to(torch.uint8)
+        valid = valid.view(torch.uint8)
     _req(valid, torch.uint8, "valid", 1)
     if xyz.shape[1] != 3 or valid.numel() != xyz.shape[0]:
         raise RuntimeError("nearest_valid_fill: xyz (n,3) and valid (n,) expected")
     n = xyz.shape[0]
     out = torch.empty(n, dtype=torch.int64, device=xyz.device)
+    if method == "sorted":
+        ws = torch.empty(lib().xm3d_nearest_valid_fill_sorted_workspace_bytes(n), dtype=torch.uint8, device=xyz.device)
+        check(lib().xm3d_nearest_valid_fill_sorted(_ptr(xyz), n, _ptr(valid), _ptr(out), _ptr(ws), _stream()), "xm3d_nearest_valid_fill_sorted")
+        return out
+    if method != "octree":
+        raise ValueError(f"nearest_valid_fill: unknown method {method!r}")
     ws = torch.empty(lib().xm3d_nearest_valid_fill_workspace_bytes(n), dtype=torch.uint8, device=xyz.device)
     check(lib().xm3d_nearest_valid_fill(_ptr(xyz), n, _ptr(valid), float(cell), _ptr(out), _ptr(ws), _stream()), "xm3d_nearest_valid_fill")
     return out
