@@ -11,7 +11,7 @@ starts = [s for s, e, k in rows if "k_mask_owner" in k]
 segs = []
 for s0 in starts:
     nxt = min([s for s in starts if s > s0] + [rows[-1][1]])
-    ends = [e for s, e, k in rows if s0 <= s < nxt and "k_nearest" in k and "seg" not in k]
+    ends = [e for s, e, k in rows if s0 <= s < nxt and ("k_ns_query" in k or ("k_nearest" in k and "seg" not in k))]
     if ends:
         segs.append((s0, max(ends)))
 agg = collections.defaultdict(lambda: [0, 0])
