@@ -127,13 +127,15 @@ def test_configuration_matches_oracle_per_stage(dev, setup, mode):
     cfg, cpu, scenes = setup
     dtype = torch.bfloat16 if mode == "bf16_bench" else torch.float32
     model = pipeline.make_inference_model(cpu, dev, dtype, channels_last=True, graphs=True)
-    sds = [pipeline.SceneOnDevice(sc, dev) for sc in scenes]
+    # bf16: 2 scenes x 5 views in ONE forward (batch 10), as bench does; fp32: one scene per forward, like bench's fp32 leg
+    # (the shipped MIOpen find-db holds the fp32 NHWC shapes at batch 5; untuned shapes cost minutes of solver search)
+    sds = [pipeline.SceneOnDevice(sc, dev) for sc in (scenes if mode == "bf16_bench" else scenes[:1])]
     vox = pipeline.default_voxelizer(cfg.voxel_size, dev)
-    batch, out = _forward_group(model, sds, vox)               # 2 scenes x 5 views in ONE forward (batch 10), as bench does
+    batch, out = _forward_group(model, sds, vox)
     off = batch["point_offsets"]
     bounds = BF16 if mode == "bf16_bench" else FP32
     worst = {}
-    for (si, v) in ((0, 0), (0, 3), (1, 2)):                    # three of the ten views through the oracle (5 s each)
+    for (si, v) in (((0, 0), (0, 3), (1, 2)) if mode == "bf16_bench" else ((0, 0), (0, 3))):   # through the oracle (5 s each)
         b = si * 5 + v
         ref = oracle_view(cpu, scenes[si], v, (si, v))
         rep = stage_report(out, b, slice(off[b], off[b + 1]), ref)

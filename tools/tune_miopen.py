@@ -13,7 +13,7 @@ dev = torch.device("cuda:0")
 cfg = load_cfg_from_cfg_file(os.path.join(ROOT, "configs", "xmask3d_scannet_B15N4.yaml"))
 torch.manual_seed(0)
 with torch.device(dev):
-    model = XMASK3d(cfg, dense_dtype=torch.bfloat16).eval()
+    model = XMASK3d(cfg, dense_dtype=torch.float32 if os.environ.get("XM3D_TUNE_DTYPE") == "fp32" else torch.bfloat16).eval()
 model = model.to(dev)
 if os.environ.get('XM3D_CL') == '1':
     model.set_channels_last(True)
