@@ -12,10 +12,13 @@ B = int(sys.argv[1]) if len(sys.argv) > 1 else 5
 dev = torch.device("cuda:0")
 cfg = load_cfg_from_cfg_file(os.path.join(ROOT, "configs", "xmask3d_scannet_B15N4.yaml"))
 torch.manual_seed(0)
-model = XMASK3d(cfg).eval().to(dev).set_dense_dtype(torch.bfloat16).set_channels_last(True)
+model = pipeline.make_inference_model(XMASK3d(cfg).eval(), dev, torch.bfloat16, channels_last=True, graphs=False)  # the bench configuration, eager
 sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
 vox = pipeline.default_voxelizer(device=dev)
-batch = pipeline.build_scene_batch(sd, list(range(B)), vox, [np.diag([50.0, 50.0, 50.0, 1.0])] * B)
+T = np.diag([50.0, 50.0, 50.0, 1.0])
+nv = len(sd.views)
+batch = pipeline.build_group_batch([(sd, list(range(nv)))] * (B // nv), vox, [[T] * nv] * (B // nv)) if B > nv else \
+    pipeline.build_scene_batch(sd, list(range(B)), vox, [T] * B)
 # label every module call so that device time can be read per module (inclusive), independent of python stack capture
 import torch.autograd.profiler as ap
 def add_hooks(root):

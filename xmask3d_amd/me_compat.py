@@ -276,10 +276,11 @@ class _ConvBase(nn.Module):
     def _kernel3(self):
         return self.kernel if self.kernel.dim() == 3 else self.kernel.unsqueeze(0)
 
-    def _packed_weight(self, k3):
-        if not ops.mfma_eligible(self.in_channels, self.out_channels):
+    def _packed_weight(self, k3, cin=None):
+        cin = self.in_channels if cin is None else cin
+        if not ops.mfma_eligible(cin, self.out_channels):
             return None
-        algo = ops.default_tiled_algo(self.in_channels, self.out_channels, self.kernel_volume)
+        algo = ops.default_tiled_algo(cin, self.out_channels, self.kernel_volume)
         key = (k3.data_ptr(), self.kernel._version, k3.device, algo)
         if self._packed_key != key:
             pack = ops.pack_weight_split if algo == ops.ALGO_SPLIT else ops.pack_weight
@@ -310,13 +311,23 @@ class _ConvBase(nn.Module):
         if not k3.is_contiguous():
             k3 = k3.contiguous()
         n_out = cm.num(ts_out)
-        packed = self._packed_weight(k3)
+        cin = self.in_channels
+        if cin < 32 and self.out_channels % 32 == 0 and self.kernel_volume > 1:
+            # the 3 -> 32 stem (mink_unet.py conv0p1s1, 5^3 offsets): zero-pad the input channels to one 32-channel MFMA step
+            # instead of the scalar kernel - same sums (the padded products are exact zeros)
+            cin = 32
+            key = (k3.data_ptr(), self.kernel._version, k3.device)
+            if getattr(self, "_padded_key", None) != key:
+                self._padded, self._padded_key = F.pad(k3, (0, 0, 0, 32 - self.in_channels)).contiguous(), key
+            k3 = self._padded
+            feats = F.pad(feats, (0, 32 - self.in_channels))
+        packed = self._packed_weight(k3, cin)
         nbr = tiles = None
         if packed is not None:
             tiles = cm.tiles(ts_in, ts_out, self.kernel_size, self.transposed)
         if not (self.kernel_volume == 1 and self.stride == 1):
             nbr = cm.kernel_map(ts_in, ts_out, self.kernel_size, self.transposed)
-        split = packed is not None and ops.default_tiled_algo(self.in_channels, self.out_channels, self.kernel_volume) == ops.ALGO_SPLIT
+        split = packed is not None and ops.default_tiled_algo(cin, self.out_channels, self.kernel_volume) == ops.ALGO_SPLIT
         pend = _PendingConv(feats, k3, packed, nbr, cm.order(ts_out), n_out, tiles, feats_split=x._Fs if split else None,
                             emit_split=split and getattr(self, "emit_split", True))
         if self.bias is not None:
