@@ -200,6 +200,10 @@ int xm3d_bias_residual_nhwc(const void* a, const void* b, const void* bias, int3
 /* GEGLU gate of ldm's FeedForward (attention.py GEGLU.forward): x (rows, 2*D) contiguous -> out (rows, D) =
  * x[:, :D] * gelu(x[:, D:]) (exact erf GELU, f32 arithmetic). */
 int xm3d_geglu(const void* x, int32_t dtype, int64_t rows, int32_t D, void* out, void* stream);
+/* probs[r, :] = softmax(scale * scores[r, :]): scores (rows, cols) f32 contiguous, probs (rows, cols) bf16; cols a multiple of
+ * 4 up to 8192, scale > 0.  The softmax of the VAE's single-head 4096 x 512 attention between its two library GEMMs (ldm
+ * AttnBlock; models/modeling/meta_arch/ldm.py:448-482) - see pointwise.hip. */
+int xm3d_softmax_rows_f32_bf16(const float* scores, int64_t rows, int32_t cols, float scale, void* probs, void* stream);
 
 /* ---- masked cross-attention bias (replaces the mask handling of Mask2Former's decoder, XMask3D copy
  * third_party/.../odise.py:395,445-491: bilinear shrink -> sigmoid -> < 0.5 -> repeat over heads -> all/and-not -> -inf fill).

@@ -99,3 +99,37 @@ def test_unsupported_inputs_are_refused(dev):
     with torch.enable_grad():
         qg = qb.clone().requires_grad_(True)
         assert not ops.attention_supported(qg, qb, qb)                        # training: autograd path
+
+
+def test_softmax_rows_matches_torch(dev):
+    from xmask3d_amd import ops
+
+    torch.manual_seed(0)
+    for rows, cols in ((7, 4096), (33, 1024), (5, 8192), (3, 12)):
+        s = torch.randn(rows, cols, device=dev) * 30
+        s[0, : cols // 2] = -1e30                                   # masked-out half a row
+        got = ops.softmax_rows(s, 0.044).float()
+        want = torch.softmax(s.double() * 0.044, -1)
+        assert (got.double() - want).abs().max().item() < 4e-3 * want.max().item() + 1e-6   # bf16 output rounding
+        assert torch.allclose(got.sum(-1), torch.ones(rows, device=dev), atol=2e-2)
+    with pytest.raises(RuntimeError):
+        ops.softmax_rows(torch.zeros(2, 10, device=dev), 1.0)       # cols % 4
+    with pytest.raises(RuntimeError):
+        ops.softmax_rows(torch.zeros(2, 16, device=dev), -1.0)
+
+
+def test_vae_attention_block_unfused_path_matches_fp32(dev):
+    """VaeAttnBlock in bf16 channels-last (two GEMMs around xm3d_softmax_rows_f32_bf16) against the same block in fp32"""
+    from xmask3d_amd.sd_model import VaeAttnBlock
+
+    torch.manual_seed(1)
+    blk = VaeAttnBlock(512).to(dev).eval()
+    x = torch.randn(2, 512, 32, 32, device=dev)
+    with torch.no_grad():
+        want = blk(x)
+        half = VaeAttnBlock(512).to(dev).eval()
+        half.load_state_dict(blk.state_dict())
+        half = half.to(torch.bfloat16).to(memory_format=torch.channels_last)
+        got = half(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)).float()
+    rel = (got - want).abs().max().item() / want.abs().max().item()
+    assert rel < 2e-2, rel

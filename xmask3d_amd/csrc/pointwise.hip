@@ -48,6 +48,63 @@ __global__ __launch_bounds__(256) void k_geglu(const T* __restrict__ x, int64_t 
     }
 }
 
+// Row softmax of f32 scores into bf16 probabilities: P[r, :] = softmax(scale * S[r, :]).  The middle step of the VAE's
+// single-head attention over 4096 positions with 512 channels (ldm's AttnBlock, reached from models/modeling/meta_arch/ldm.py:
+// 448-482): at that head width the two products are plain large GEMMs (hipBLASLt, 0.4 ms each at 20 views) and the unfused
+// form - f32 scores written once, read once here - beats the fused library kernel (2.6 ms) by ~1 ms per call; the scores
+// stay f32 up to the exponential like in a flash kernel, only P is rounded to bf16 (as a flash kernel does before P V).
+// One workgroup per row, the row held in registers (cols <= 256 * 4 * SM_VPT): one read + one write, HBM-bound.
+constexpr int SM_VPT = 8;  // float4 per thread: rows up to 8192 columns
+__global__ __launch_bounds__(256) void k_softmax_rows(const float* __restrict__ S, int32_t cols, float scale_log2e,
+                                                      __hip_bfloat16* __restrict__ P) {
+    __shared__ float red[4];
+    const float* row = S + int64_t(blockIdx.x) * cols;
+    __hip_bfloat16* out = P + int64_t(blockIdx.x) * cols;
+    const int nv = cols >> 2, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float4 v[SM_VPT];
+    float m = -INFINITY;
+#pragma unroll
+    for (int i = 0; i < SM_VPT; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < nv) {
+            v[i] = reinterpret_cast<const float4*>(row)[e];
+            m = fmaxf(m, fmaxf(fmaxf(v[i].x, v[i].y), fmaxf(v[i].z, v[i].w)));
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+    if (lane == 0) red[wave] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3])) * scale_log2e;  // scale > 0: max commutes with it
+    __syncthreads();
+    float sum = 0.f;
+#pragma unroll
+    for (int i = 0; i < SM_VPT; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < nv) {
+            v[i].x = exp2f(fmaf(v[i].x, scale_log2e, -m));
+            v[i].y = exp2f(fmaf(v[i].y, scale_log2e, -m));
+            v[i].z = exp2f(fmaf(v[i].z, scale_log2e, -m));
+            v[i].w = exp2f(fmaf(v[i].w, scale_log2e, -m));
+            sum += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) sum += __shfl_xor(sum, off);
+    if (lane == 0) red[wave] = sum;
+    __syncthreads();
+    const float inv = 1.f / ((red[0] + red[1]) + (red[2] + red[3]));
+#pragma unroll
+    for (int i = 0; i < SM_VPT; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        if (e < nv) {
+            __hip_bfloat16 o[4] = {__float2bfloat16(v[i].x * inv), __float2bfloat16(v[i].y * inv), __float2bfloat16(v[i].z * inv),
+                                   __float2bfloat16(v[i].w * inv)};
+            reinterpret_cast<uint2*>(out)[e] = *reinterpret_cast<const uint2*>(o);
+        }
+    }
+}
+
 static unsigned grid_for(int64_t nvec) {
     int64_t blocks = (nvec + 255) / 256;
     return unsigned(blocks > 8192 ? 8192 : (blocks < 1 ? 1 : blocks));
@@ -94,6 +151,18 @@ extern "C" int xm3d_geglu(const void* x, int32_t dtype, int64_t rows, int32_t D,
     else
         hipLaunchKernelGGL(k_geglu<__hip_bfloat16>, dim3(grid_for(nvec)), dim3(256), 0, s, static_cast<const __hip_bfloat16*>(x), rows,
                            D / N, static_cast<__hip_bfloat16*>(out));
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+extern "C" int xm3d_softmax_rows_f32_bf16(const float* scores, int64_t rows, int32_t cols, float scale, void* probs, void* stream) {
+    XM3D_REQUIRE(rows >= 0 && rows < (1ll << 31) && cols >= 4 && cols % 4 == 0 && cols <= 256 * 4 * SM_VPT && scale > 0.f,
+                 "softmax_rows: rows=%lld, cols=%d (multiple of 4, <= %d), scale=%g > 0 expected", (long long)rows, cols, 256 * 4 * SM_VPT,
+                 double(scale));
+    if (rows == 0) return XM3D_OK;
+    XM3D_REQUIRE(scores && probs, "softmax_rows: null pointer");
+    hipLaunchKernelGGL(k_softmax_rows, dim3(unsigned(rows)), dim3(256), 0, as_stream(stream), scores, cols, scale * 1.4426950408889634f,
+                       static_cast<__hip_bfloat16*>(probs));
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }

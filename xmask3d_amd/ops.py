@@ -453,6 +453,16 @@ def attn_mask_bias_supported(shape, size):
     return H % h == 0 and W % w == 0 and (H // h) % 2 == 0 and (W // w) % 2 == 0 and h * w <= 8192
 
 
+def softmax_rows(scores, scale):
+    """scores (..., cols) f32 contiguous -> bf16 softmax(scale * scores) over the last dimension (cols % 4 == 0, <= 8192)"""
+    _req(scores, torch.float32, "scores")
+    out = torch.empty(scores.shape, dtype=torch.bfloat16, device=scores.device)
+    cols = scores.shape[-1]
+    check(lib().xm3d_softmax_rows_f32_bf16(_ptr(scores), scores.numel() // cols, cols, float(scale), _ptr(out), _stream()),
+          "xm3d_softmax_rows_f32_bf16")
+    return out
+
+
 def geglu(x):
     """x (..., 2D) contiguous f32/bf16 device tensor -> (..., D) = x[..., :D] * gelu(x[..., D:])"""
     if not x.is_cuda or x.dtype not in (torch.float32, torch.bfloat16) or not x.is_contiguous() or x.shape[-1] % 2:
