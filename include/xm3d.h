@@ -191,6 +191,12 @@ int xm3d_group_norm(const void* x, int32_t dtype, int64_t B, int32_t C, int32_t 
 int xm3d_group_norm_nhwc(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,
                          int32_t G, const void* gamma, const void* beta, float eps, int32_t silu, void* y, double* stats_ws,
                          void* stream);
+/* ... with a residual (B, H*W, C) or NULL added after the affine and before the activation: y = act(GN(x + shift) + residual) -
+ * the tail of detectron2's BottleneckBlock in the projection bottlenecks, relu(conv3_norm(out) + shortcut)
+ * (backbone/feature_extractor.py:40-47), in the apply pass instead of an add and a ReLU pass of their own. */
+int xm3d_group_norm_nhwc_res(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,
+                             int32_t G, const void* gamma, const void* beta, float eps, int32_t silu, const void* residual, void* y,
+                             double* stats_ws, void* stream);
 
 /* ---- pointwise fusions around the frozen nets' convolutions / GEMMs (channels-last, dtype 0 = f32, 1 = bf16) ----
  * out = a + b + bias[c] over (pixels, C) NHWC tensors; a may be NULL (out = b + bias).  Replaces the separate broadcast
@@ -200,6 +206,9 @@ int xm3d_bias_residual_nhwc(const void* a, const void* b, const void* bias, int3
 /* GEGLU gate of ldm's FeedForward (attention.py GEGLU.forward): x (rows, 2*D) contiguous -> out (rows, D) =
  * x[:, :D] * gelu(x[:, D:]) (exact erf GELU, f32 arithmetic). */
 int xm3d_geglu(const void* x, int32_t dtype, int64_t rows, int32_t D, void* out, void* stream);
+/* out = x * sigmoid(1.702 x) (QuickGELU of CLIP's MLPs, meta_arch/clip.py via open_clip), f32 / bf16 contiguous, numel a
+ * multiple of 4 / 8; in place allowed. */
+int xm3d_quick_gelu(const void* x, int32_t dtype, int64_t numel, void* out, void* stream);
 /* probs[r, :] = softmax(scale * scores[r, :]): scores (rows, cols) f32 contiguous, probs (rows, cols) bf16; cols a multiple of
  * 4 up to 8192, scale > 0.  The softmax of the VAE's single-head 4096 x 512 attention between its two library GEMMs (ldm
  * AttnBlock; models/modeling/meta_arch/ldm.py:448-482) - see pointwise.hip. */

@@ -133,3 +133,16 @@ def test_vae_attention_block_unfused_path_matches_fp32(dev):
         got = half(x.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)).float()
     rel = (got - want).abs().max().item() / want.abs().max().item()
     assert rel < 2e-2, rel
+
+
+def test_quick_gelu_matches_expression(dev):
+    from xmask3d_amd import ops
+
+    torch.manual_seed(2)
+    x = torch.randn(3, 307, 4096, device=dev) * 4
+    assert torch.allclose(ops.quick_gelu(x), x * torch.sigmoid(1.702 * x), atol=1e-6, rtol=1e-5)
+    xb = x.to(torch.bfloat16)
+    want = (xb.float() * torch.sigmoid(1.702 * xb.float()))
+    assert (ops.quick_gelu(xb).float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item()
+    with pytest.raises(TypeError):
+        ops.quick_gelu(x.transpose(0, 2))

@@ -127,6 +127,14 @@ def test_fused_group_norm_matches_torch(dev, dtype, shape, act):
     yc = ops.group_norm(xc, 32, w.to(dev).to(dtype), b.to(dev).to(dtype), 1e-6, act)
     assert yc.is_contiguous(memory_format=torch.channels_last) and yc.shape == x.shape
     assert (yc.float().cpu() - ref).abs().max().item() <= max(tol, 2e-5) * max(ref.abs().max().item(), 1.0)
+    # residual added after the affine, before the activation (bottleneck tail): NHWC kernel and the NCHW fallback
+    r = torch.randn(shape)
+    pre = torch.nn.functional.group_norm(x.to(dtype).float(), 32, w.to(dtype).float(), b.to(dtype).float(), 1e-6) + r.to(dtype).float()
+    ref_r = pre * torch.sigmoid(pre) if act == 1 else (torch.relu(pre) if act == 2 else pre)
+    rc = r.to(dev).to(dtype).contiguous(memory_format=torch.channels_last)
+    for xin, rin in ((xc, rc), (x.to(dev).to(dtype), r.to(dev).to(dtype))):
+        yr = ops.group_norm(xin, 32, w.to(dev).to(dtype), b.to(dev).to(dtype), 1e-6, act, residual=rin)
+        assert (yr.float().cpu() - ref_r).abs().max().item() <= max(2 * tol, 2e-5) * max(ref_r.abs().max().item(), 1.0)
 
 
 def test_nearest_index_is_exact(dev):

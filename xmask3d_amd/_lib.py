@@ -53,6 +53,8 @@ _SIGS = {
     "xm3d_bn_bwd_apply": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_group_norm": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp, c_vp]),
     "xm3d_group_norm_nhwc": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp, c_vp]),
+    "xm3d_group_norm_nhwc_res": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp,
+                                              c_vp, c_vp]),
     "xm3d_bias_residual_nhwc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "xm3d_attn_mask_bias": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "xm3d_attention_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
@@ -60,6 +62,7 @@ _SIGS = {
     "xm3d_linear_sum_assignment": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_compute_mapping": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, ctypes.c_double, c_vp, c_vp]),
     "xm3d_geglu": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
+    "xm3d_quick_gelu": (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp, c_vp]),
     "xm3d_softmax_rows_f32_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, ctypes.c_float, c_vp, c_vp]),
     "xm3d_nearest_index": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_nearest_index_segmented": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_vp, c_vp]),

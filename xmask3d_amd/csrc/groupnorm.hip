@@ -159,13 +159,14 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_gn_apply_nhwc(const T* __restrict__ x, const T* __restrict__ shift, int shift_bstride,
                                                        const T* __restrict__ gamma, const T* __restrict__ beta, const double* __restrict__ stats,
                                                        int hw, int C, int cg, int G, int slabs, int pix, float inv_elems, float eps, int silu,
-                                                       T* __restrict__ y) {
+                                                       const T* __restrict__ residual, T* __restrict__ y) {
     constexpr int N = VecIO<T>::N;
     const int b = blockIdx.x / slabs, slab = blockIdx.x % slabs;
     const int vpp = C / N;
     const int p0 = slab * pix;
     const int p1 = (p0 + pix < hw) ? p0 + pix : hw;
     const T* xb = x + int64_t(b) * hw * C;
+    const T* rb = residual ? residual + int64_t(b) * hw * C : nullptr;  // added after the affine, before the activation
     T* yb = y + int64_t(b) * hw * C;
     for (int v = threadIdx.x % (vpp < 256 ? vpp : 256); v < vpp; v += 256) {
         const int lanes = vpp < 256 ? 256 / vpp : 1;
@@ -196,11 +197,13 @@ __global__ __launch_bounds__(256) void k_gn_apply_nhwc(const T* __restrict__ x, 
             c[j] = fmaf(sh[j] - mean, a[j], be[j]);
         }
         for (int p = p0 + pl; p < p1; p += lanes) {
-            float val[N];
+            float val[N], res[N];
             VecIO<T>::load(xb + int64_t(p) * C + v * N, val);
+            if (rb) VecIO<T>::load(rb + int64_t(p) * C + v * N, res);
 #pragma unroll
             for (int j = 0; j < N; ++j) {
                 float t = fmaf(val[j], a[j], c[j]);
+                if (rb) t += res[j];
                 if (silu == 1) t = t / (1.f + __expf(-t));
                 else if (silu == 2) t = fmaxf(t, 0.f);
                 val[j] = t;
@@ -212,7 +215,7 @@ __global__ __launch_bounds__(256) void k_gn_apply_nhwc(const T* __restrict__ x, 
 
 template <typename T>
 static int gn_launch_nhwc(const void* x, const void* shift, int shift_bstride, int64_t B, int C, int hw, int G, const void* gamma, const void* beta, float eps, int silu,
-                          void* y, double* stats, hipStream_t s) {
+                          const void* residual, void* y, double* stats, hipStream_t s) {
     const int cg = C / G;
     const int nstat = int(B) * G * 2;
     hipLaunchKernelGGL(k_gn_zero, dim3((nstat + 255) / 256), dim3(256), 0, s, stats, nstat);
@@ -227,7 +230,7 @@ static int gn_launch_nhwc(const void* x, const void* shift, int shift_bstride, i
     hipLaunchKernelGGL(k_gn_stats_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift), shift_bstride, hw, C, cg, G, slabs, int(pix), stats);
     hipLaunchKernelGGL(k_gn_apply_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift),
                        shift_bstride, static_cast<const T*>(gamma), static_cast<const T*>(beta), stats, hw, C, cg, G, slabs, int(pix),
-                       1.0f / (float(cg) * float(hw)), eps, silu, static_cast<T*>(y));
+                       1.0f / (float(cg) * float(hw)), eps, silu, static_cast<const T*>(residual), static_cast<T*>(y));
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
@@ -268,9 +271,9 @@ extern "C" int xm3d_group_norm(const void* x, int32_t dtype, int64_t B, int32_t 
     return gn_launch<__hip_bfloat16>(x, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
 }
 
-extern "C" int xm3d_group_norm_nhwc(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,
-                                    int32_t G, const void* gamma, const void* beta, float eps, int32_t silu, void* y, double* stats_ws,
-                                    void* stream) {
+extern "C" int xm3d_group_norm_nhwc_res(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C,
+                                        int32_t hw, int32_t G, const void* gamma, const void* beta, float eps, int32_t silu,
+                                        const void* residual, void* y, double* stats_ws, void* stream) {
     XM3D_REQUIRE(B >= 0 && C >= 1 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "group_norm_nhwc: bad shape B=%lld C=%d hw=%d G=%d",
                  (long long)B, C, hw, G);
     XM3D_REQUIRE(dtype == 0 || dtype == 1, "group_norm_nhwc: dtype must be 0 (f32) or 1 (bf16)");
@@ -279,10 +282,16 @@ extern "C" int xm3d_group_norm_nhwc(const void* x, const void* shift, int32_t sh
     const int N = dtype == 0 ? 4 : 8;
     XM3D_REQUIRE(C % N == 0, "group_norm_nhwc: C=%d must be a multiple of %d", C, N);
     XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) |
-                   reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0,
+                   reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0,
                  "group_norm_nhwc: tensors must be 16-byte aligned");
     XM3D_REQUIRE(shift_bstride == 0 || shift_bstride == C, "group_norm_nhwc: shift_bstride must be 0 (shared) or C (per sample)");
     hipStream_t s = as_stream(stream);
-    if (dtype == 0) return gn_launch_nhwc<float>(x, shift, shift_bstride, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
-    return gn_launch_nhwc<__hip_bfloat16>(x, shift, shift_bstride, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
+    if (dtype == 0) return gn_launch_nhwc<float>(x, shift, shift_bstride, B, C, hw, G, gamma, beta, eps, silu, residual, y, stats_ws, s);
+    return gn_launch_nhwc<__hip_bfloat16>(x, shift, shift_bstride, B, C, hw, G, gamma, beta, eps, silu, residual, y, stats_ws, s);
+}
+
+extern "C" int xm3d_group_norm_nhwc(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,
+                                    int32_t G, const void* gamma, const void* beta, float eps, int32_t silu, void* y, double* stats_ws,
+                                    void* stream) {
+    return xm3d_group_norm_nhwc_res(x, shift, shift_bstride, dtype, B, C, hw, G, gamma, beta, eps, silu, nullptr, y, stats_ws, stream);
 }

@@ -48,6 +48,21 @@ __global__ __launch_bounds__(256) void k_geglu(const T* __restrict__ x, int64_t 
     }
 }
 
+// QuickGELU of CLIP's MLPs (meta_arch/clip.py -> open_clip's QuickGELU: x * sigmoid(1.702 x)): one pass instead of the three
+// elementwise kernels of the expression (scalar multiply, sigmoid, multiply), evaluated in f32 and rounded once.
+template <typename T>
+__global__ __launch_bounds__(256) void k_quick_gelu(const T* __restrict__ x, int64_t nvec, T* __restrict__ out) {
+    constexpr int N = VecIO<T>::N;
+    const int64_t stride = int64_t(gridDim.x) * blockDim.x;
+    for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < nvec; e += stride) {
+        float v[N];
+        VecIO<T>::load(x + e * N, v);
+#pragma unroll
+        for (int j = 0; j < N; ++j) v[j] = v[j] / (1.f + __expf(-1.702f * v[j]));
+        VecIO<T>::store(out + e * N, v);
+    }
+}
+
 // Row softmax of f32 scores into bf16 probabilities: P[r, :] = softmax(scale * S[r, :]).  The middle step of the VAE's
 // single-head attention over 4096 positions with 512 channels (ldm's AttnBlock, reached from models/modeling/meta_arch/ldm.py:
 // 448-482): at that head width the two products are plain large GEMMs (hipBLASLt, 0.4 ms each at 20 views) and the unfused
@@ -163,6 +178,24 @@ extern "C" int xm3d_softmax_rows_f32_bf16(const float* scores, int64_t rows, int
     XM3D_REQUIRE(scores && probs, "softmax_rows: null pointer");
     hipLaunchKernelGGL(k_softmax_rows, dim3(unsigned(rows)), dim3(256), 0, as_stream(stream), scores, cols, scale * 1.4426950408889634f,
                        static_cast<__hip_bfloat16*>(probs));
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+extern "C" int xm3d_quick_gelu(const void* x, int32_t dtype, int64_t numel, void* out, void* stream) {
+    XM3D_REQUIRE(dtype == 0 || dtype == 1, "quick_gelu: dtype must be 0 (f32) or 1 (bf16)");
+    const int N = dtype == 0 ? 4 : 8;
+    XM3D_REQUIRE(numel >= 0 && numel % N == 0, "quick_gelu: numel=%lld must be a multiple of %d", (long long)numel, N);
+    if (numel == 0) return XM3D_OK;
+    XM3D_REQUIRE(x && out, "quick_gelu: null pointer");
+    const int64_t nvec = numel / N;
+    hipStream_t s = as_stream(stream);
+    if (dtype == 0)
+        hipLaunchKernelGGL(k_quick_gelu<float>, dim3(grid_for(nvec)), dim3(256), 0, s, static_cast<const float*>(x), nvec,
+                           static_cast<float*>(out));
+    else
+        hipLaunchKernelGGL(k_quick_gelu<__hip_bfloat16>, dim3(grid_for(nvec)), dim3(256), 0, s, static_cast<const __hip_bfloat16*>(x), nvec,
+                           static_cast<__hip_bfloat16*>(out));
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }

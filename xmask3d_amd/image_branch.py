@@ -242,8 +242,10 @@ class _ConvGN(nn.Conv2d):
         self.norm = nn.GroupNorm(32, cout)
         self._relu = relu
 
-    def forward(self, x):
-        return gn_act(self.norm, super().forward(x), ACT_RELU if self._relu else ACT_NONE)
+    def forward(self, x, residual=None, relu=None):
+        """residual / relu: the tail of the bottleneck, relu(norm(conv(x)) + residual), in the GroupNorm's apply pass"""
+        relu = self._relu if relu is None else relu
+        return gn_act(self.norm, super().forward(x), ACT_RELU if relu else ACT_NONE, residual=residual)
 
 
 class GNBottleneck(nn.Module):
@@ -255,8 +257,8 @@ class GNBottleneck(nn.Module):
         self.conv3 = _ConvGN(bottleneck, cout, 1)
 
     def forward(self, x):
-        out = self.conv3(self.conv2(self.conv1(x)))
-        return F.relu_(out + (self.shortcut(x) if self.shortcut is not None else x))
+        # detectron2 BottleneckBlock: relu(conv3(...) + shortcut); add + ReLU ride in conv3's GroupNorm apply pass
+        return self.conv3(self.conv2(self.conv1(x)), residual=self.shortcut(x) if self.shortcut is not None else x, relu=True)
 
 
 class FeatureExtractorBackbone(nn.Module):
@@ -292,8 +294,14 @@ class FeatureExtractorBackbone(nn.Module):
         out = {}
         for name, stride, indices in self._groups:
             acc = None
+            size = (input_image_size[-2] // stride, input_image_size[-1] // stride)
             for idx in indices:
-                f = F.interpolate(features[idx], size=(input_image_size[-2] // stride, input_image_size[-1] // stride))
+                f = features[idx]
+                if tuple(f.shape[-2:]) != size:  # (same size: nearest resampling is the identity - no launch, no copy)
+                    # outside autocast: there the resampling would run in f32 (a cast before and one after, 0.35 ms each at
+                    # 20 x 512 x 128^2); nearest neighbour only moves values, bf16 in / bf16 out is exact
+                    with torch.autocast(device_type=f.device.type, enabled=False):
+                        f = F.interpolate(f, size=size)
                 p = self.feature_projections[idx](f)
                 acc = p if acc is None else acc + p
             out[name] = acc

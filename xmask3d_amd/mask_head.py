@@ -243,7 +243,7 @@ class SelfAttentionLayer(nn.Module):
             if ops.attention_supported(q4, k4, v4):
                 o = torch.empty((L, B, E), dtype=q4.dtype, device=tgt.device)
                 ops.attention(q4, k4, v4, out=o.view(L, B, H, E // H).transpose(0, 1))
-                return self.norm(tgt + F.linear(o, mha.out_proj.weight, mha.out_proj.bias))
+                return self.norm(tgt + F.linear(o, mha.out_proj.weight, mha.out_proj.bias).float())  # (.float(): a mixed f32 + bf16 add of this size takes the 35 us generic kernel)
         return self.norm(tgt + self.self_attn(q, k, value=tgt, need_weights=False)[0])
 
 
@@ -279,7 +279,7 @@ class CrossAttentionLayer(nn.Module):
             # output written straight in (Lq, B, E) order for the out-projection
             o = torch.empty((Lq, B, E), dtype=q.dtype, device=q.device)
             ops.attention(q4, k4, v4, bias=memory_bias.view(B, 1, Lq, Lk), out=o.view(Lq, B, H, E // H).transpose(0, 1))
-            return self.norm(tgt + F.linear(o, mha.out_proj.weight, mha.out_proj.bias))
+            return self.norm(tgt + F.linear(o, mha.out_proj.weight, mha.out_proj.bias).float())  # (.float(): a mixed f32 + bf16 add of this size takes the 35 us generic kernel)
         q = q.view(Lq, B, H, E // H).permute(1, 2, 0, 3)
         k = k.view(Lk, B, H, E // H).permute(1, 2, 0, 3)
         v = v.view(Lk, B, H, E // H).permute(1, 2, 0, 3)
@@ -299,7 +299,7 @@ class FFNLayer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, tgt):
-        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))))
+        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))).float())
 
 
 class MLP(nn.Module):

@@ -384,10 +384,16 @@ def is_nhwc(x):
     return x.dim() == 4 and x.is_cuda and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
 
 
-def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False, shift=None):
+def _act_torch(y, act):
+    act = int(act)
+    return y * torch.sigmoid(y) if act == 1 else (torch.relu_(y) if act == 2 else y)
+
+
+def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False, shift=None, residual=None):
     """NCHW, channels-last or (B,C,L) f32/bf16 device tensor -> same shape/dtype/layout; statistics in f64, math in f32.
     silu: False/0 none, True/1 SiLU, 2 ReLU fused after the affine.
-    shift: optional (C,) or (B,C) term added to x before normalising (conv bias / embedding term folded in)."""
+    shift: optional (C,) or (B,C) term added to x before normalising (conv bias / embedding term folded in).
+    residual: optional tensor like x added after the affine, before the activation (channels-last kernel; else a torch add)."""
     if not x.is_cuda:
         raise RuntimeError("group_norm: ROCm device tensor required (no CPU path)")
     if x.dtype not in (torch.float32, torch.bfloat16):
@@ -407,9 +413,13 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False, shif
             if shift.numel() not in (C, B * C):
                 raise TypeError("group_norm: shift must have C or B*C elements")
             bstride = C if (shift.numel() == B * C and B > 1) else 0
-        check(lib().xm3d_group_norm_nhwc(_ptr(x), _ptr(shift), bstride, 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups,
-                                         _ptr(weight), _ptr(bias), float(eps), int(silu), _ptr(y), _ptr(stats), _stream()),
-              "xm3d_group_norm_nhwc")
+        fused_res = residual is not None and residual.dtype == x.dtype and residual.shape == x.shape and is_nhwc(residual)
+        check(lib().xm3d_group_norm_nhwc_res(_ptr(x), _ptr(shift), bstride, 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups,
+                                             _ptr(weight), _ptr(bias), float(eps), 0 if (residual is not None and not fused_res) else int(silu),
+                                             _ptr(residual if fused_res else None), _ptr(y), _ptr(stats), _stream()),
+              "xm3d_group_norm_nhwc_res")
+        if residual is not None and not fused_res:
+            y = _act_torch(y + residual, silu)
         return y
     if shift is not None:
         x = x + shift.to(x.dtype).reshape(-1, C, *([1] * (x.dim() - 2)))
@@ -417,8 +427,8 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False, shif
         x = x.contiguous()
     y = torch.empty_like(x)
     check(lib().xm3d_group_norm(_ptr(x), 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups, _ptr(weight), _ptr(bias),
-                                float(eps), int(silu), _ptr(y), _ptr(stats), _stream()), "xm3d_group_norm")
-    return y
+                                float(eps), 0 if residual is not None else int(silu), _ptr(y), _ptr(stats), _stream()), "xm3d_group_norm")
+    return y if residual is None else _act_torch(y + residual, silu)
 
 
 def bias_residual(a, b, bias):
@@ -451,6 +461,15 @@ def attn_mask_bias_supported(shape, size):
     H, W = shape[-2:]
     h, w = int(size[0]), int(size[1])
     return H % h == 0 and W % w == 0 and (H // h) % 2 == 0 and (W // w) % 2 == 0 and h * w <= 8192
+
+
+def quick_gelu(x):
+    """x * sigmoid(1.702 x) in one pass (f32 / bf16 contiguous device tensor, numel % 8 == 0)"""
+    if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_cuda or not x.is_contiguous():
+        raise TypeError("quick_gelu: contiguous f32/bf16 device tensor required")
+    out = torch.empty_like(x)
+    check(lib().xm3d_quick_gelu(_ptr(x), 0 if x.dtype == torch.float32 else 1, x.numel(), _ptr(out), _stream()), "xm3d_quick_gelu")
+    return out
 
 
 def softmax_rows(scores, scale):

@@ -57,10 +57,11 @@ def bias_residual(skip, h, bias):
     return ops.bias_residual(skip, h, bias.to(h.dtype))
 
 
-def gn_act(norm: nn.GroupNorm, x, act=ACT_NONE, shift=None):
+def gn_act(norm: nn.GroupNorm, x, act=ACT_NONE, shift=None, residual=None):
     """GroupNorm followed by an activation.  Inference on a ROCm device runs the fused HIP kernel (xm3d_group_norm:
     two streaming passes instead of five library kernels); under autograd, or on the CPU-baseline path, the torch ops.
-    shift: (C,) or (B,C) term added to x first (a folded conv bias / embedding term)."""
+    shift: (C,) or (B,C) term added to x first (a folded conv bias / embedding term).
+    residual: tensor like x added after the normalisation, before the activation: act(GN(x) + residual)."""
     if x.is_cuda and not torch.is_grad_enabled() and x.dtype in (torch.float32, torch.bfloat16) and (
             (x.numel() // (x.shape[0] * x.shape[1])) % 8 == 0 or (x.dim() == 4 and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 8 == 0)):
         from . import ops
@@ -68,10 +69,14 @@ def gn_act(norm: nn.GroupNorm, x, act=ACT_NONE, shift=None):
         w, b = norm.weight, norm.bias
         if w is not None and w.dtype != x.dtype:
             w, b = w.to(x.dtype), b.to(x.dtype)
-        return ops.group_norm(x, norm.num_groups, w, b, norm.eps, act, shift)
+        if residual is not None and residual.dtype != x.dtype:
+            residual = residual.to(x.dtype)
+        return ops.group_norm(x, norm.num_groups, w, b, norm.eps, act, shift, residual)
     if shift is not None:
         x = x + shift.to(x.dtype).reshape(-1, x.shape[1], 1, 1)
     y = norm(x)
+    if residual is not None:
+        y = y + residual
     if act == ACT_SILU:
         return y * torch.sigmoid(y)
     return F.relu(y) if act == ACT_RELU else y
