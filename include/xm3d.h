@@ -206,6 +206,10 @@ int xm3d_bias_residual_nhwc(const void* a, const void* b, const void* bias, int3
 /* GEGLU gate of ldm's FeedForward (attention.py GEGLU.forward): x (rows, 2*D) contiguous -> out (rows, D) =
  * x[:, :D] * gelu(x[:, D:]) (exact erf GELU, f32 arithmetic). */
 int xm3d_geglu(const void* x, int32_t dtype, int64_t rows, int32_t D, void* out, void* stream);
+/* out (B, H + pad_bottom, W + pad_right, C) <- zero-padded channels-last x (B, H, W, C); C a multiple of 4 (f32) / 8 (bf16).
+ * The (0, 1, 0, 1) padding of ldm's VAE Downsample in one pass instead of F.pad's fill + strided copy. */
+int xm3d_pad_nhwc(const void* x, int32_t dtype, int64_t B, int32_t H, int32_t W, int32_t C, int32_t pad_bottom, int32_t pad_right, void* out,
+                  void* stream);
 /* out = x * sigmoid(1.702 x) (QuickGELU of CLIP's MLPs, meta_arch/clip.py via open_clip), f32 / bf16 contiguous, numel a
  * multiple of 4 / 8; in place allowed. */
 int xm3d_quick_gelu(const void* x, int32_t dtype, int64_t numel, void* out, void* stream);

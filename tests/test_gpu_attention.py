@@ -146,3 +146,17 @@ def test_quick_gelu_matches_expression(dev):
     assert (ops.quick_gelu(xb).float() - want).abs().max().item() <= 2 ** -8 * want.abs().max().item()
     with pytest.raises(TypeError):
         ops.quick_gelu(x.transpose(0, 2))
+
+
+def test_pad_nhwc_matches_f_pad(dev):
+    import torch.nn.functional as F
+    from xmask3d_amd import ops
+
+    torch.manual_seed(3)
+    for dtype, shape in ((torch.bfloat16, (2, 128, 30, 22)), (torch.float32, (1, 8, 5, 7))):
+        x = torch.randn(shape, device=dev).to(dtype).contiguous(memory_format=torch.channels_last)
+        y = ops.pad_bottom_right_nhwc(x, 1, 1)
+        assert y.is_contiguous(memory_format=torch.channels_last) and torch.equal(y, F.pad(x, (0, 1, 0, 1)))
+        assert torch.equal(ops.pad_bottom_right_nhwc(x, 0, 3), F.pad(x, (0, 3, 0, 0)))
+    with pytest.raises(TypeError):
+        ops.pad_bottom_right_nhwc(torch.zeros(1, 8, 4, 4, device=dev), 1, 1)   # NCHW

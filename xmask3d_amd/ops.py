@@ -463,6 +463,17 @@ def attn_mask_bias_supported(shape, size):
     return H % h == 0 and W % w == 0 and (H // h) % 2 == 0 and (W // w) % 2 == 0 and h * w <= 8192
 
 
+def pad_bottom_right_nhwc(x, pad_bottom, pad_right):
+    """channels-last (B,C,H,W) f32/bf16 device tensor -> (B,C,H+pad_bottom,W+pad_right) channels-last, zero padded, one pass"""
+    if x.dtype not in (torch.float32, torch.bfloat16) or not is_nhwc(x):
+        raise TypeError("pad_bottom_right_nhwc: channels-last f32/bf16 device tensor required")
+    B, C, H, W = x.shape
+    out = torch.empty((B, C, H + pad_bottom, W + pad_right), dtype=x.dtype, device=x.device, memory_format=torch.channels_last)
+    check(lib().xm3d_pad_nhwc(_ptr(x), 0 if x.dtype == torch.float32 else 1, B, H, W, C, int(pad_bottom), int(pad_right), _ptr(out), _stream()),
+          "xm3d_pad_nhwc")
+    return out
+
+
 def quick_gelu(x):
     """x * sigmoid(1.702 x) in one pass (f32 / bf16 contiguous device tensor, numel % 8 == 0)"""
     if x.dtype not in (torch.float32, torch.bfloat16) or not x.is_cuda or not x.is_contiguous():

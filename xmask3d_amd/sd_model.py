@@ -94,15 +94,23 @@ class VaeResBlock(nn.Module):
         if cin != cout:
             self.nin_shortcut = nn.Conv2d(cin, cout, 1)
 
-    def forward(self, x, temb=None):
+    def forward(self, x, temb=None, pend=None):
+        """pend: (C,) bias of the convolution that produced x and has NOT been added yet (conv_in / Downsample / Upsample of
+        the fused channels-last path): it rides in norm1's shift and in the residual add instead of a pass of its own."""
         if fused_nhwc(x):  # conv1's bias rides in norm2's shift, conv2's (and the shortcut's) in the residual add
-            h = conv_nobias(self.conv1, gn_act(self.norm1, x, ACT_SILU))
+            h = conv_nobias(self.conv1, gn_act(self.norm1, x, ACT_SILU, pend))
             h = conv_nobias(self.conv2, gn_act(self.norm2, h, ACT_SILU, self.conv1.bias))
             bias = self.conv2.bias
             if self.in_channels != self.out_channels:
                 x = conv_nobias(self.nin_shortcut, x)
                 bias = bias + self.nin_shortcut.bias
+                if pend is not None:  # the 1x1 shortcut of a constant: W @ pend
+                    bias = bias + self.nin_shortcut.weight.flatten(1) @ pend.to(self.nin_shortcut.weight.dtype)
+            elif pend is not None:
+                bias = bias + pend
             return bias_residual(x, h, bias)
+        if pend is not None:
+            x = x + pend.to(x.dtype).view(1, -1, 1, 1)
         h = self.conv1(gn_act(self.norm1, x, ACT_SILU))
         h = self.conv2(gn_act(self.norm2, h, ACT_SILU))
         if self.in_channels != self.out_channels:
@@ -146,8 +154,15 @@ class VaeDownsample(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
 
-    def forward(self, x):
-        return self.conv(F.pad(x, (0, 1, 0, 1)))
+    def forward(self, x, defer_bias=False):
+        """defer_bias: return (conv output WITHOUT its bias, bias) when the fused channels-last path applies, else (out, None)"""
+        if fused_nhwc(x) and not torch.is_grad_enabled():
+            xp = ops.pad_bottom_right_nhwc(x, 1, 1)  # one pass instead of F.pad's fill + strided copy
+            if defer_bias:
+                return conv_nobias(self.conv, xp), self.conv.bias
+            return self.conv(xp)
+        out = self.conv(F.pad(x, (0, 1, 0, 1)))
+        return (out, None) if defer_bias else out
 
 
 class VaeUpsample(nn.Module):
@@ -155,8 +170,12 @@ class VaeUpsample(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
-    def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+    def forward(self, x, defer_bias=False):
+        up = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        if defer_bias and fused_nhwc(up):
+            return conv_nobias(self.conv, up), self.conv.bias
+        out = self.conv(up)
+        return (out, None) if defer_bias else out
 
 
 class _Level(nn.Module):
@@ -199,14 +218,21 @@ class VaeEncoder(nn.Module):
     def forward(self, x, taps=()):
         """taps: flat block indices (level*num_res_blocks + block) whose input is recorded."""
         feats = []
-        h = self.conv_in(x)
+        # fused channels-last inference: the bias of conv_in / every Downsample conv is not added by a pass of its own (PyTorch-
+        # ROCm adds a conv bias in a separate broadcast kernel, 0.53 ms at 20 x 512^2 x 128) but handed to the next ResBlock
+        h, pend = conv_nobias(self.conv_in, x), self.conv_in.bias
+        if not fused_nhwc(h):
+            h, pend = h + pend.to(h.dtype).view(1, -1, 1, 1), None
         for i, lvl in enumerate(self.down):
             for j, blk in enumerate(lvl.block):
                 if i * self.num_res_blocks + j in taps:
+                    if pend is not None:
+                        h, pend = h + pend.to(h.dtype).view(1, -1, 1, 1), None
                     feats.append(h)
-                h = blk(h)
+                h, pend = blk(h, pend=pend), None
             if i != self.num_resolutions - 1:
-                h = lvl.downsample(h)
+                h, pend = lvl.downsample(h, defer_bias=True)
+        assert pend is None
         h = self.mid(h)
         return self.conv_out(gn_act(self.norm_out, h, ACT_SILU)), feats
 
@@ -234,17 +260,20 @@ class VaeDecoder(nn.Module):
         feats = []
         h = self.mid(self.conv_in(z))
         idx = 0
+        pend = None
         last = max(taps) if taps else -1
         for i in reversed(range(self.num_resolutions)):
             for blk in self.up[i].block:
                 if idx in taps:
+                    if pend is not None:
+                        h, pend = h + pend.to(h.dtype).view(1, -1, 1, 1), None
                     feats.append(h)
                     if stop_after_taps and idx == last:
                         return None, feats
-                h = blk(h)
+                h, pend = blk(h, pend=pend), None
                 idx += 1
             if i != 0:
-                h = self.up[i].upsample(h)
+                h, pend = self.up[i].upsample(h, defer_bias=True)  # bias handed to the next level's first ResBlock
         return self.conv_out(gn_act(self.norm_out, h, ACT_SILU)), feats
 
 
@@ -384,8 +413,12 @@ class UNetUpsample(nn.Module):
         super().__init__()
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
-    def forward(self, x):
-        return self.conv(F.interpolate(x, scale_factor=2.0, mode="nearest"))
+    def forward(self, x, defer_bias=False):
+        up = F.interpolate(x, scale_factor=2.0, mode="nearest")
+        if defer_bias and fused_nhwc(up):
+            return conv_nobias(self.conv, up), self.conv.bias
+        out = self.conv(up)
+        return (out, None) if defer_bias else out
 
 
 class TimestepSeq(nn.Sequential):
