@@ -21,6 +21,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .sd_model import ACT_NONE, ACT_RELU, gn_act
 from .msda import MSDeformAttn
 
 
@@ -146,11 +147,23 @@ class _Conv(nn.Conv2d):
             self.norm = nn.GroupNorm(32, cout)
         self._gn, self._relu = gn, relu
 
-    def forward(self, x):
+    def forward(self, x, residual=None):
+        """residual: added after the norm, before the ReLU (the FPN's top-down term rides in the GroupNorm apply pass)"""
         x = super().forward(x)
         if self._gn:
+            if _fused_inference(x):
+                # bf16 inference under autocast: the fused channels-last GroupNorm(+residual)(+ReLU) kernel, bf16 out - the
+                # next convolution would round torch's f32 GroupNorm output to bf16 anyway
+                return gn_act(self.norm, x, ACT_RELU if self._relu else ACT_NONE, residual=residual)
             x = self.norm(x)
+        if residual is not None:
+            x = x + residual
         return F.relu_(x) if self._relu else x
+
+
+def _fused_inference(x):
+    return x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.bfloat16 and x.dim() == 4 \
+        and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
 
 
 def _c2_xavier_fill(m):
@@ -201,8 +214,13 @@ class MSDeformAttnPixelDecoder(nn.Module):
 
     def forward_features(self, features):
         srcs, pos = [], []
+        low = torch.is_autocast_enabled("cuda") and not torch.is_grad_enabled()
+
+        def f32(t):  # `.float()` as the reference does (msdeformattn.py:320) - except where autocast would round the result
+            return t if (low and t.dtype == torch.bfloat16) else t.float()   # straight back to bf16 for the convolution
+
         for idx, f in enumerate(self.transformer_in_features[::-1]):
-            x = features[f].float()  # deformable attention is f32 in the reference too (msdeformattn.py:320)
+            x = f32(features[f])
             srcs.append(self.input_proj[idx](x))
             pos.append(self.pe_layer(x))
         y, shapes, level_start_index = self.transformer(srcs, pos)
@@ -210,8 +228,16 @@ class MSDeformAttnPixelDecoder(nn.Module):
         sizes = [h * w for h, w in shapes]
         out = [z.transpose(1, 2).reshape(bs, -1, h, w) for z, (h, w) in zip(torch.split(y, sizes, dim=1), shapes)]
         for idx, f in enumerate(self.in_features[: self.num_fpn_levels][::-1]):
-            cur = self.lateral_convs[idx](features[f].float())
-            y = cur + F.interpolate(out[-1], size=cur.shape[-2:], mode="bilinear", align_corners=False)
+            x = f32(features[f])
+            if low and _fused_inference(x):
+                # lateral conv -> GroupNorm with the top-down term as the kernel's residual: y = GN(conv(x)) + up
+                with torch.autocast(device_type="cuda", enabled=False):  # bilinear resampling in bf16, not via f32 copies
+                    up = F.interpolate(out[-1].to(torch.bfloat16).contiguous(memory_format=torch.channels_last), size=x.shape[-2:],
+                                       mode="bilinear", align_corners=False)
+                y = self.lateral_convs[idx](x, residual=up)
+            else:
+                cur = self.lateral_convs[idx](x)
+                y = cur + F.interpolate(out[-1], size=cur.shape[-2:], mode="bilinear", align_corners=False)
             out.append(self.output_convs[idx](y))
         return self.mask_features(out[-1]), out[0], out[: self.maskformer_num_feature_levels]
 
