@@ -117,7 +117,21 @@ __global__ __launch_bounds__(256) void k_gn_stats_nhwc(const T* __restrict__ x, 
 #pragma unroll
         for (int j = 0; j < N; ++j) s[j] = ss[j] = sh[j] = 0.f;
         if (shift) VecIO<T>::load(shift + int64_t(b) * shift_bstride + v * N, sh);
-        for (int p = p0 + pl; p < p1; p += lanes) {
+        int p = p0 + pl;
+        for (; p + 3 * lanes < p1; p += 4 * lanes) {  // four independent 16-byte loads in flight per lane
+            float val[4][N];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) VecIO<T>::load(base + int64_t(p + u * lanes) * C + v * N, val[u]);
+#pragma unroll
+            for (int u = 0; u < 4; ++u)
+#pragma unroll
+                for (int j = 0; j < N; ++j) {
+                    const float t = val[u][j] + sh[j];
+                    s[j] += t;
+                    ss[j] = fmaf(t, t, ss[j]);
+                }
+        }
+        for (; p < p1; p += lanes) {
             float val[N];
             VecIO<T>::load(base + int64_t(p) * C + v * N, val);
 #pragma unroll
@@ -196,7 +210,26 @@ __global__ __launch_bounds__(256) void k_gn_apply_nhwc(const T* __restrict__ x, 
             a[j] = rstd * ga[j];
             c[j] = fmaf(sh[j] - mean, a[j], be[j]);
         }
-        for (int p = p0 + pl; p < p1; p += lanes) {
+        int p = p0 + pl;
+        if (!rb) {
+            for (; p + 3 * lanes < p1; p += 4 * lanes) {  // four independent 16-byte loads in flight per lane
+                float val[4][N];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) VecIO<T>::load(xb + int64_t(p + u * lanes) * C + v * N, val[u]);
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+#pragma unroll
+                    for (int j = 0; j < N; ++j) {
+                        float t = fmaf(val[u][j], a[j], c[j]);
+                        if (silu == 1) t = t / (1.f + __expf(-t));
+                        else if (silu == 2) t = fmaxf(t, 0.f);
+                        val[u][j] = t;
+                    }
+                    VecIO<T>::store(yb + int64_t(p + u * lanes) * C + v * N, val[u]);
+                }
+            }
+        }
+        for (; p < p1; p += lanes) {
             float val[N], res[N];
             VecIO<T>::load(xb + int64_t(p) * C + v * N, val);
             if (rb) VecIO<T>::load(rb + int64_t(p) * C + v * N, res);
