@@ -206,6 +206,12 @@ int xm3d_bias_residual_nhwc(const void* a, const void* b, const void* bias, int3
 /* GEGLU gate of ldm's FeedForward (attention.py GEGLU.forward): x (rows, 2*D) contiguous -> out (rows, D) =
  * x[:, :D] * gelu(x[:, D:]) (exact erf GELU, f32 arithmetic). */
 int xm3d_geglu(const void* x, int32_t dtype, int64_t rows, int32_t D, void* out, void* stream);
+/* LayerNorm over the last dimension with an optional residual add in front: s = x (+ delta); y = LN(s) * gamma + beta.
+ * x, delta, sum_out, y: (rows, C) contiguous, gamma / beta (C) or NULL, all of dtype 0 = f32 / 1 = bf16; C a multiple of 4 / 8
+ * up to 2048 / 4096.  sum_out (needs delta): receives s, the new residual stream (y then normalises s as stored).  The
+ * LayerNorms of ldm's BasicTransformerBlock and open_clip's ResidualAttentionBlock (meta_arch/ldm.py:425-446, clip.py). */
+int xm3d_layer_norm(const void* x, const void* delta, int32_t dtype, int64_t rows, int32_t C, const void* gamma, const void* beta, float eps,
+                    void* sum_out, void* y, void* stream);
 /* out (B, H + pad_bottom, W + pad_right, C) <- zero-padded channels-last x (B, H, W, C); C a multiple of 4 (f32) / 8 (bf16).
  * The (0, 1, 0, 1) padding of ldm's VAE Downsample in one pass instead of F.pad's fill + strided copy. */
 int xm3d_pad_nhwc(const void* x, int32_t dtype, int64_t B, int32_t H, int32_t W, int32_t C, int32_t pad_bottom, int32_t pad_right, void* out,

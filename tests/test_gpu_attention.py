@@ -160,3 +160,29 @@ def test_pad_nhwc_matches_f_pad(dev):
         assert torch.equal(ops.pad_bottom_right_nhwc(x, 0, 3), F.pad(x, (0, 3, 0, 0)))
     with pytest.raises(TypeError):
         ops.pad_bottom_right_nhwc(torch.zeros(1, 8, 4, 4, device=dev), 1, 1)   # NCHW
+
+
+@pytest.mark.parametrize("dtype,rows,C", [(torch.bfloat16, 4096 * 2 + 3, 320), (torch.bfloat16, 307 * 3, 1024), (torch.float32, 1001, 256),
+                                           (torch.bfloat16, 17, 4096), (torch.bfloat16, 5, 8)])
+def test_layer_norm_kernel_matches_torch(dev, dtype, rows, C):
+    import torch.nn.functional as F
+    from xmask3d_amd import ops
+
+    torch.manual_seed(C)
+    x = (torch.randn(rows, C, device=dev) * 3 + 1).to(dtype)
+    d = torch.randn(rows, C, device=dev).to(dtype)
+    w, b = (torch.rand(C, device=dev) + 0.5).to(dtype), torch.randn(C, device=dev).to(dtype)
+    tol = 1e-5 if dtype == torch.float32 else 2 ** -7
+    want = F.layer_norm(x.float(), (C,), w.float(), b.float(), 1e-5)
+    got = ops.layer_norm(x, w, b, 1e-5)
+    assert got.dtype == dtype and (got.float() - want).abs().max().item() <= tol * max(want.abs().max().item(), 1.0)
+    s_want = (x + d)                                                    # the residual stream in the storage dtype
+    y, s = ops.layer_norm(x, w, b, 1e-5, delta=d, want_sum=True)
+    assert torch.equal(s, s_want)
+    want = F.layer_norm(s_want.float(), (C,), w.float(), b.float(), 1e-5)
+    assert (y.float() - want).abs().max().item() <= tol * max(want.abs().max().item(), 1.0)
+    y2 = ops.layer_norm(x, None, None, 1e-5, delta=d)                   # no affine, sum not requested
+    want = F.layer_norm((x.float() + d.float()), (C,), None, None, 1e-5)
+    assert (y2.float() - want).abs().max().item() <= 2 * tol * max(want.abs().max().item(), 1.0)
+    with pytest.raises(TypeError):
+        ops.layer_norm(x[:, : C - 4] if C > 8 else x.t(), None, None)

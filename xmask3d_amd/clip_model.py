@@ -73,6 +73,12 @@ class ResidualAttentionBlock(nn.Module):
         return self.attn.out_proj(o.transpose(1, 2).reshape(b, t, c))
 
     def forward(self, x, allow=None):
+        n1, n2 = self.ln_1, self.ln_2
+        if ops.layer_norm_supported(x, x.shape[-1]) and n1.weight.dtype == x.dtype:
+            # inference: HIP LayerNorm (xm3d_layer_norm); the residual add in front of ln_2 rides in its kernel
+            a = self.attention(ops.layer_norm(x, n1.weight, n1.bias, n1.eps), allow)
+            h, x = ops.layer_norm(x, n2.weight, n2.bias, n2.eps, delta=a.contiguous(), want_sum=True)
+            return x + self.mlp(h)
         x = x + self.attention(self.ln_1(x), allow)
         return x + self.mlp(self.ln_2(x))
 

@@ -463,6 +463,34 @@ def attn_mask_bias_supported(shape, size):
     return H % h == 0 and W % w == 0 and (H // h) % 2 == 0 and (W // w) % 2 == 0 and h * w <= 8192
 
 
+def _layer_norm_ok(x, C):
+    return (x.is_cuda and x.dtype in (torch.float32, torch.bfloat16) and x.is_contiguous() and x.shape[-1] == C and C % 8 == 0
+            and C <= (2048 if x.dtype == torch.float32 else 4096))
+
+
+def layer_norm_supported(x, C):
+    """callers' gate: inference (no autograd graph wanted) on tensors xm3d_layer_norm takes as they are"""
+    return not torch.is_grad_enabled() and _layer_norm_ok(x, C)
+
+
+def layer_norm(x, weight, bias, eps=1e-5, delta=None, want_sum=False):
+    """LayerNorm over the last dimension of a contiguous f32/bf16 device tensor (statistics in f32).  delta: tensor like x added
+    first (the residual add in front of a pre-norm LayerNorm); want_sum: also return x + delta -> (y, x + delta)."""
+    C = x.shape[-1]
+    if not _layer_norm_ok(x, C):
+        raise TypeError("layer_norm: contiguous f32/bf16 device tensor with C % 8 == 0 (<= 4096 bf16 / 2048 f32) required")
+    for t in (weight, bias, delta):
+        if t is not None and (t.dtype != x.dtype or not t.is_contiguous()):
+            raise TypeError("layer_norm: weight / bias / delta must be contiguous tensors of the input dtype")
+    if delta is not None and delta.shape != x.shape:
+        raise TypeError("layer_norm: delta must have the shape of x")
+    y = torch.empty_like(x)
+    s = torch.empty_like(x) if (want_sum and delta is not None) else None
+    check(lib().xm3d_layer_norm(_ptr(x), _ptr(delta), 0 if x.dtype == torch.float32 else 1, x.numel() // C, C, _ptr(weight), _ptr(bias),
+                                float(eps), _ptr(s), _ptr(y), _stream()), "xm3d_layer_norm")
+    return (y, s) if want_sum else y
+
+
 def pad_bottom_right_nhwc(x, pad_bottom, pad_right):
     """channels-last (B,C,H,W) f32/bf16 device tensor -> (B,C,H+pad_bottom,W+pad_right) channels-last, zero padded, one pass"""
     if x.dtype not in (torch.float32, torch.bfloat16) or not is_nhwc(x):

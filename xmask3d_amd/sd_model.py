@@ -375,6 +375,14 @@ class BasicTransformerBlock(nn.Module):
         self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
 
     def forward(self, x, context):
+        n1, n2, n3 = self.norm1, self.norm2, self.norm3
+        if ops.layer_norm_supported(x, x.shape[-1]) and n1.weight.dtype == x.dtype:
+            # inference: HIP LayerNorm (xm3d_layer_norm); the residual adds in front of norm2 / norm3 ride in their kernels
+            a = self.attn1(ops.layer_norm(x, n1.weight, n1.bias, n1.eps))
+            h, x = ops.layer_norm(x, n2.weight, n2.bias, n2.eps, delta=a.contiguous(), want_sum=True)
+            a = self.attn2(h, context)
+            h, x = ops.layer_norm(x, n3.weight, n3.bias, n3.eps, delta=a.contiguous(), want_sum=True)
+            return self.ff(h) + x
         x = self.attn1(self.norm1(x)) + x
         x = self.attn2(self.norm2(x), context) + x
         return self.ff(self.norm3(x)) + x
