@@ -113,11 +113,31 @@ class MSDeformAttn(nn.Module):
             value = value.masked_fill(input_padding_mask[..., None], float(0))
         H, L, P = self.n_heads, self.n_levels, self.n_points
         value = value.view(N, Len_in, H, self.d_model // H)
-        offsets = self.sampling_offsets(query).view(N, Len_q, H, L, P, 2)
-        weights = F.softmax(self.attention_weights(query).view(N, Len_q, H, L * P), -1).view(N, Len_q, H, L, P)
+        fast = query.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled("cuda")
+        if fast:
+            # bf16 inference under autocast: the two projections of `query` as ONE GEMM on one bf16 copy of it (autocast casts
+            # the activation once per linear), concatenated weight cached per parameter version
+            so, aw = self.sampling_offsets, self.attention_weights
+            key = (so.weight.data_ptr(), so.weight._version, aw.weight.data_ptr(), aw.weight._version, so.weight.device)
+            if getattr(self, "_cat_key", None) != key:
+                dt = torch.get_autocast_dtype("cuda")
+                self._cat_w = torch.cat([so.weight.detach(), aw.weight.detach()]).to(dt).contiguous()
+                self._cat_b = torch.cat([so.bias.detach(), aw.bias.detach()]).to(dt).contiguous()
+                self._cat_key = key
+            ow = F.linear(query.to(self._cat_w.dtype), self._cat_w, self._cat_b)
+            n_off = H * L * P * 2
+            offsets = ow[..., :n_off].float().view(N, Len_q, H, L, P, 2)
+            weights = F.softmax(ow[..., n_off:].float().view(N, Len_q, H, L * P), -1).view(N, Len_q, H, L, P)
+        else:
+            offsets = self.sampling_offsets(query).view(N, Len_q, H, L, P, 2)
+            weights = F.softmax(self.attention_weights(query).view(N, Len_q, H, L * P), -1).view(N, Len_q, H, L, P)
         if reference_points.shape[-1] == 2:
             normalizer = torch.stack([input_spatial_shapes[..., 1], input_spatial_shapes[..., 0]], -1)
-            loc = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
+            if fast:  # reference + offsets / normalizer in one pass
+                loc = torch.addcdiv(reference_points[:, :, None, :, None, :].float(), offsets,
+                                    normalizer[None, None, None, :, None, :].to(offsets.dtype))
+            else:
+                loc = reference_points[:, :, None, :, None, :] + offsets / normalizer[None, None, None, :, None, :]
         elif reference_points.shape[-1] == 4:
             loc = reference_points[:, :, None, :, None, :2] + offsets / P * reference_points[:, :, None, :, None, 2:] * 0.5
         else:
