@@ -142,6 +142,15 @@ def kernel_rooflines(dev):
     out.append({"kernel": "xm3d::k_nearest", "bound": "valu", "achieved": fl / (ms * 1e-3) / 1e12, "peak": FP32_MFMA_PEAK_TF,
                 "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF, "avg_launch_us": ms * 1e3,
                 "note": "brute force 120 k x 40 k, 3 sub + 3 fma + compare per pair; peak = f32 vector rate"})
+    # the same question as the pipeline asks it (every invalid point <- nearest valid point), Morton-sorted and tile-pruned:
+    # no closed-form roofline (the work depends on the geometry); reported as time and as the scan-equivalent pair rate
+    pts = torch.cat([q, r])
+    valid = torch.cat([torch.zeros(q.shape[0], dtype=torch.bool, device=dev), torch.ones(r.shape[0], dtype=torch.bool, device=dev)])
+    ms2 = event_ms(lambda: ops.nearest_valid_fill(pts, valid, method="sorted"), 10)
+    out.append({"kernel": "xm3d_nearest_valid_fill_sorted (k_ns_query + sort)", "bound": "valu", "achieved": fl / (ms2 * 1e-3) / 1e12,
+                "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s (scan-equivalent)", "frac": None, "avg_launch_us": ms2 * 1e3,
+                "note": "same 120 k queries / 40 k references (uniform random cloud): exact answer with a fraction of the pair tests; "
+                        "scan-equivalent rate = what the brute-force scan would need to match this time"})
     return out
 
 
