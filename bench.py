@@ -231,7 +231,8 @@ def main():
                     help="training iterations timed after the inference steps (1 view per GPU, DDP when --gpus > 1), reported under "
                          "\"train\" (fp32 as the reference trains, plus a bf16-frozen-nets run); 0 = skip")
     ap.add_argument("--fp32-steps", type=int, default=4, help="inference steps of the fp32 configuration reported under \"fp32\" (0 = skip)")
-    ap.add_argument("--scene-pool", type=int, default=4, help="distinct seeded scenes the timed loop cycles through")
+    ap.add_argument("--scene-pool", type=int, default=8,
+                    help="distinct seeded scenes the timed loop cycles through (8 = two different 4-scene groups alternate)")
     ap.add_argument("--nchw", action="store_true", help="keep NCHW activations in the frozen conv nets (default: channels-last)")
     ap.add_argument("--no-graph", action="store_true", help="launch the dense branch eagerly instead of replaying a HIP graph")
     ap.add_argument("--faithful-dead-compute", action="store_true", help="also run what the reference computes and discards")
