@@ -198,6 +198,17 @@ int xm3d_group_norm_nhwc_res(const void* x, const void* shift, int32_t shift_bst
                              int32_t G, const void* gamma, const void* beta, float eps, int32_t silu, const void* residual, void* y,
                              double* stats_ws, void* stream);
 
+/* out = a + b + bias[c] like xm3d_bias_residual_nhwc, plus the GroupNorm statistics of `out` (sum, sum of squares per (sample,
+ * group), over the values as stored) into stats (B*G*2 doubles, zeroed here): the GroupNorm that consumes `out` next - norm1 of
+ * the following ResBlock, the norm of an attention block - then runs xm3d_group_norm_nhwc_apply with them and skips its
+ * statistics pass.  a may be NULL; (B, H*W, C) channels-last, C a multiple of 4 (f32) / 8 (bf16), G <= 64. */
+int xm3d_bias_residual_stats_nhwc(const void* a, const void* b, const void* bias, int32_t dtype, int64_t B, int32_t C, int32_t hw, int32_t G,
+                                  void* out, double* stats, void* stream);
+/* The apply pass of xm3d_group_norm_nhwc_res alone, on statistics the caller already holds (of x + shift if a shift is given). */
+int xm3d_group_norm_nhwc_apply(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,
+                               int32_t G, const void* gamma, const void* beta, float eps, int32_t silu, const void* residual, void* y,
+                               const double* stats, void* stream);
+
 /* ---- pointwise fusions around the frozen nets' convolutions / GEMMs (channels-last, dtype 0 = f32, 1 = bf16) ----
  * out = a + b + bias[c] over (pixels, C) NHWC tensors; a may be NULL (out = b + bias).  Replaces the separate broadcast
  * bias kernel PyTorch-ROCm appends to every MIOpen convolution plus the residual add (ldm ResnetBlock.forward `x + h`). */

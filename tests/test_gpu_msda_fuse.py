@@ -137,6 +137,34 @@ def test_fused_group_norm_matches_torch(dev, dtype, shape, act):
         assert (yr.float().cpu() - ref_r).abs().max().item() <= max(2 * tol, 2e-5) * max(ref_r.abs().max().item(), 1.0)
 
 
+@pytest.mark.parametrize("dtype,shape", [(torch.bfloat16, (3, 128, 32, 24)), (torch.float32, (2, 64, 16, 16)), (torch.bfloat16, (2, 320, 64, 64))])
+def test_bias_residual_carries_group_norm_statistics(dev, dtype, shape):
+    """xm3d_bias_residual_stats_nhwc: same sum as the plain kernel, and the GroupNorm that follows (apply pass only, on the
+    statistics taken on the way) equals the GroupNorm that computes its own"""
+    from xmask3d_amd import ops
+
+    torch.manual_seed(shape[1])
+    a, b = (torch.randn(shape, device=dev).to(dtype).contiguous(memory_format=torch.channels_last) for _ in range(2))
+    bias = torch.randn(shape[1], device=dev).to(dtype)
+    w, g = (torch.rand(shape[1], device=dev) + 0.5).to(dtype), torch.randn(shape[1], device=dev).to(dtype)
+    plain = ops.bias_residual(a, b, bias)
+    carried = ops.bias_residual(a, b, bias, stats_groups=32)
+    assert torch.equal(plain, carried) and getattr(carried, "_xm3d_gn_stats", None) is not None and not hasattr(plain, "_xm3d_gn_stats")
+    for act in (0, 1):
+        want = ops.group_norm(plain, 32, w, g, 1e-6, act)
+        got = ops.group_norm(carried, 32, w, g, 1e-6, act)
+        tol = 1e-5 if dtype == torch.float32 else 2 ** -7     # f32 partial sums in a different order: a last-digit effect
+        assert (got.float() - want.float()).abs().max().item() <= tol * max(want.float().abs().max().item(), 1.0)
+    # a shift (folded conv bias) or another group count invalidates the carried statistics: the full kernel runs
+    # (the statistics are atomically accumulated partial sums: equal up to the last digit, not bit for bit)
+    sh = torch.randn(shape[1], device=dev).to(dtype)
+    close = lambda p, q: (p.float() - q.float()).abs().max().item() <= tol * max(q.float().abs().max().item(), 1.0)
+    assert close(ops.group_norm(carried, 32, w, g, 1e-6, 1, sh), ops.group_norm(plain, 32, w, g, 1e-6, 1, sh))
+    assert close(ops.group_norm(carried, 16, w, g, 1e-6, 1), ops.group_norm(plain, 16, w, g, 1e-6, 1))
+    none = ops.bias_residual(None, b, bias, stats_groups=32)
+    assert torch.equal(none, ops.bias_residual(None, b, bias))
+
+
 def test_nearest_index_is_exact(dev):
     from xmask3d_amd import ops
 

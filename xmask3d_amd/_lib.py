@@ -55,6 +55,9 @@ _SIGS = {
     "xm3d_group_norm_nhwc": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp, c_vp]),
     "xm3d_group_norm_nhwc_res": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp,
                                               c_vp, c_vp]),
+    "xm3d_bias_residual_stats_nhwc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
+    "xm3d_group_norm_nhwc_apply": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp,
+                                                c_vp, c_vp]),
     "xm3d_bias_residual_nhwc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "xm3d_attn_mask_bias": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "xm3d_attention_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,

@@ -165,6 +165,73 @@ __global__ __launch_bounds__(256) void k_gn_stats_nhwc(const T* __restrict__ x, 
     }
 }
 
+// out = a + b + bias[c] (the residual add that closes a ResBlock, k_bias_residual of pointwise.hip) with the GroupNorm
+// statistics of `out` accumulated on the way: the next block's first GroupNorm then skips its statistics pass (one read of the
+// activation saved).  Same thread mapping as k_gn_stats_nhwc; the sums are taken over the values AS STORED (rounded to T).
+template <typename T>
+__global__ __launch_bounds__(256) void k_bias_residual_stats(const T* __restrict__ a, const T* __restrict__ bsrc, const T* __restrict__ bias, int hw,
+                                                             int C, int cg, int G, int slabs, int pix, T* __restrict__ out,
+                                                             double* __restrict__ stats) {
+    constexpr int N = VecIO<T>::N;
+    __shared__ float sm[2 * 64];  // G <= 64
+    const int b = blockIdx.x / slabs, slab = blockIdx.x % slabs;
+    if (threadIdx.x < 2 * G) sm[threadIdx.x] = 0.f;
+    __syncthreads();
+    const int vpp = C / N;
+    const int p0 = slab * pix;
+    const int p1 = (p0 + pix < hw) ? p0 + pix : hw;
+    const int64_t base = int64_t(b) * hw * C;
+    for (int v = threadIdx.x % (vpp < 256 ? vpp : 256); v < vpp; v += 256) {
+        const int lanes = vpp < 256 ? 256 / vpp : 1;
+        const int pl = vpp < 256 ? threadIdx.x / vpp : 0;
+        if (pl >= lanes) continue;
+        float s[N], ss[N], bi[N];
+#pragma unroll
+        for (int j = 0; j < N; ++j) s[j] = ss[j] = bi[j] = 0.f;
+        if (bias) VecIO<T>::load(bias + v * N, bi);
+        for (int p = p0 + pl; p < p1; p += lanes) {
+            const int64_t off = base + int64_t(p) * C + v * N;
+            float val[N], sk[N];
+            VecIO<T>::load(bsrc + off, val);
+            if (a) VecIO<T>::load(a + off, sk);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                float t = val[j] + bi[j];
+                if (a) t += sk[j];
+                val[j] = t;
+            }
+            VecIO<T>::store(out + off, val);
+#pragma unroll
+            for (int j = 0; j < N; ++j) {
+                const float t = sizeof(T) == 2 ? __bfloat162float(__float2bfloat16(val[j])) : val[j];
+                s[j] += t;
+                ss[j] = fmaf(t, t, ss[j]);
+            }
+        }
+        int gprev = (v * N) / cg;
+        float as = 0.f, ass = 0.f;
+#pragma unroll
+        for (int j = 0; j < N; ++j) {
+            const int g = (v * N + j) / cg;
+            if (g != gprev) {
+                atomicAdd(&sm[2 * gprev], as);
+                atomicAdd(&sm[2 * gprev + 1], ass);
+                as = ass = 0.f;
+                gprev = g;
+            }
+            as += s[j];
+            ass += ss[j];
+        }
+        atomicAdd(&sm[2 * gprev], as);
+        atomicAdd(&sm[2 * gprev + 1], ass);
+    }
+    __syncthreads();
+    if (threadIdx.x < G) {
+        atomicAdd(&stats[(int64_t(b) * G + threadIdx.x) * 2], double(sm[2 * threadIdx.x]));
+        atomicAdd(&stats[(int64_t(b) * G + threadIdx.x) * 2 + 1], double(sm[2 * threadIdx.x + 1]));
+    }
+}
+
 // Apply pass, same thread mapping as the statistics pass: a thread owns one 16-byte channel vector column, so the
 // per-channel terms fold into y = act(x * a + c) with a = rstd * gamma, c = (shift - mean) * rstd * gamma + beta computed
 // ONCE per thread; the pixel loop is load - fma - (exp) - store with no index arithmetic (a flat grid-stride loop paid two
@@ -248,10 +315,10 @@ __global__ __launch_bounds__(256) void k_gn_apply_nhwc(const T* __restrict__ x, 
 
 template <typename T>
 static int gn_launch_nhwc(const void* x, const void* shift, int shift_bstride, int64_t B, int C, int hw, int G, const void* gamma, const void* beta, float eps, int silu,
-                          const void* residual, void* y, double* stats, hipStream_t s) {
+                          const void* residual, void* y, double* stats, hipStream_t s, bool have_stats = false) {
     const int cg = C / G;
     const int nstat = int(B) * G * 2;
-    hipLaunchKernelGGL(k_gn_zero, dim3((nstat + 255) / 256), dim3(256), 0, s, stats, nstat);
+    if (!have_stats) hipLaunchKernelGGL(k_gn_zero, dim3((nstat + 255) / 256), dim3(256), 0, s, stats, nstat);
     // pixels per workgroup: aim at ~1024 workgroups, at least one pixel per pixel lane, at most 256
     const int vpp = C / VecIO<T>::N;
     const int lanes = vpp < 256 ? 256 / vpp : 1;
@@ -260,10 +327,30 @@ static int gn_launch_nhwc(const void* x, const void* shift, int shift_bstride, i
     if (pix > 256) pix = 256;
     if (pix > hw) pix = hw;
     const int slabs = int((hw + pix - 1) / pix);
-    hipLaunchKernelGGL(k_gn_stats_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift), shift_bstride, hw, C, cg, G, slabs, int(pix), stats);
+    if (!have_stats)
+        hipLaunchKernelGGL(k_gn_stats_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift), shift_bstride, hw, C, cg, G, slabs, int(pix), stats);
     hipLaunchKernelGGL(k_gn_apply_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift),
                        shift_bstride, static_cast<const T*>(gamma), static_cast<const T*>(beta), stats, hw, C, cg, G, slabs, int(pix),
                        1.0f / (float(cg) * float(hw)), eps, silu, static_cast<const T*>(residual), static_cast<T*>(y));
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+template <typename T>
+static int bias_residual_stats_launch(const void* a, const void* b, const void* bias, int64_t B, int C, int hw, int G, void* out, double* stats,
+                                      hipStream_t s) {
+    const int cg = C / G;
+    const int nstat = int(B) * G * 2;
+    hipLaunchKernelGGL(k_gn_zero, dim3((nstat + 255) / 256), dim3(256), 0, s, stats, nstat);
+    const int vpp = C / VecIO<T>::N;
+    const int lanes = vpp < 256 ? 256 / vpp : 1;
+    int64_t pix = (B * int64_t(hw) + 1023) / 1024;
+    if (pix < lanes) pix = lanes;
+    if (pix > 256) pix = 256;
+    if (pix > hw) pix = hw;
+    const int slabs = int((hw + pix - 1) / pix);
+    hipLaunchKernelGGL(k_bias_residual_stats<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(a), static_cast<const T*>(b),
+                       static_cast<const T*>(bias), hw, C, cg, G, slabs, int(pix), static_cast<T*>(out), stats);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
@@ -327,4 +414,40 @@ extern "C" int xm3d_group_norm_nhwc(const void* x, const void* shift, int32_t sh
                                     int32_t G, const void* gamma, const void* beta, float eps, int32_t silu, void* y, double* stats_ws,
                                     void* stream) {
     return xm3d_group_norm_nhwc_res(x, shift, shift_bstride, dtype, B, C, hw, G, gamma, beta, eps, silu, nullptr, y, stats_ws, stream);
+}
+
+extern "C" int xm3d_bias_residual_stats_nhwc(const void* a, const void* b, const void* bias, int32_t dtype, int64_t B, int32_t C, int32_t hw,
+                                             int32_t G, void* out, double* stats, void* stream) {
+    XM3D_REQUIRE(B >= 0 && C >= 1 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "bias_residual_stats: bad shape B=%lld C=%d hw=%d G=%d",
+                 (long long)B, C, hw, G);
+    XM3D_REQUIRE(dtype == 0 || dtype == 1, "bias_residual_stats: dtype must be 0 (f32) or 1 (bf16)");
+    if (B == 0) return XM3D_OK;
+    XM3D_REQUIRE(b && out && stats, "bias_residual_stats: null pointer");
+    const int N = dtype == 0 ? 4 : 8;
+    XM3D_REQUIRE(C % N == 0, "bias_residual_stats: C=%d must be a multiple of %d", C, N);
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(a) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(bias) |
+                   reinterpret_cast<uintptr_t>(out)) & 15) == 0, "bias_residual_stats: tensors must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    if (dtype == 0) return bias_residual_stats_launch<float>(a, b, bias, B, C, hw, G, out, stats, s);
+    return bias_residual_stats_launch<__hip_bfloat16>(a, b, bias, B, C, hw, G, out, stats, s);
+}
+
+extern "C" int xm3d_group_norm_nhwc_apply(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C,
+                                          int32_t hw, int32_t G, const void* gamma, const void* beta, float eps, int32_t silu,
+                                          const void* residual, void* y, const double* stats, void* stream) {
+    XM3D_REQUIRE(B >= 0 && C >= 1 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "group_norm_nhwc_apply: bad shape B=%lld C=%d hw=%d G=%d",
+                 (long long)B, C, hw, G);
+    XM3D_REQUIRE(dtype == 0 || dtype == 1, "group_norm_nhwc_apply: dtype must be 0 (f32) or 1 (bf16)");
+    if (B == 0) return XM3D_OK;
+    XM3D_REQUIRE(x && y && stats, "group_norm_nhwc_apply: null pointer");
+    const int N = dtype == 0 ? 4 : 8;
+    XM3D_REQUIRE(C % N == 0, "group_norm_nhwc_apply: C=%d must be a multiple of %d", C, N);
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) |
+                   reinterpret_cast<uintptr_t>(beta) | reinterpret_cast<uintptr_t>(shift) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0,
+                 "group_norm_nhwc_apply: tensors must be 16-byte aligned");
+    XM3D_REQUIRE(shift_bstride == 0 || shift_bstride == C, "group_norm_nhwc_apply: shift_bstride must be 0 (shared) or C (per sample)");
+    hipStream_t s = as_stream(stream);
+    double* st = const_cast<double*>(stats);
+    if (dtype == 0) return gn_launch_nhwc<float>(x, shift, shift_bstride, B, C, hw, G, gamma, beta, eps, silu, residual, y, st, s, true);
+    return gn_launch_nhwc<__hip_bfloat16>(x, shift, shift_bstride, B, C, hw, G, gamma, beta, eps, silu, residual, y, st, s, true);
 }

@@ -414,6 +414,16 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False, shif
                 raise TypeError("group_norm: shift must have C or B*C elements")
             bstride = C if (shift.numel() == B * C and B > 1) else 0
         fused_res = residual is not None and residual.dtype == x.dtype and residual.shape == x.shape and is_nhwc(residual)
+        pre = getattr(x, "_xm3d_gn_stats", None)
+        if pre is not None and shift is None and pre[1] == num_groups and pre[2] == x.data_ptr():
+            # statistics already taken by the kernel that produced x (xm3d_bias_residual_stats_nhwc): apply pass only
+            check(lib().xm3d_group_norm_nhwc_apply(_ptr(x), None, 0, 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups, _ptr(weight),
+                                                   _ptr(bias), float(eps), 0 if (residual is not None and not fused_res) else int(silu),
+                                                   _ptr(residual if fused_res else None), _ptr(y), _ptr(pre[0]), _stream()),
+                  "xm3d_group_norm_nhwc_apply")
+            if residual is not None and not fused_res:
+                y = _act_torch(y + residual, silu)
+            return y
         check(lib().xm3d_group_norm_nhwc_res(_ptr(x), _ptr(shift), bstride, 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups,
                                              _ptr(weight), _ptr(bias), float(eps), 0 if (residual is not None and not fused_res) else int(silu),
                                              _ptr(residual if fused_res else None), _ptr(y), _ptr(stats), _stream()),
@@ -431,14 +441,23 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False, shif
     return y if residual is None else _act_torch(y + residual, silu)
 
 
-def bias_residual(a, b, bias):
-    """out = a + b + bias[c] for channels-last (B,C,H,W) f32/bf16 device tensors; a may be None."""
+def bias_residual(a, b, bias, stats_groups=None):
+    """out = a + b + bias[c] for channels-last (B,C,H,W) f32/bf16 device tensors; a may be None.
+    stats_groups: G of the GroupNorm expected to read the result (its statistics are then computed here, on the way)."""
     if not is_nhwc(b) or (a is not None and (not is_nhwc(a) or a.shape != b.shape or a.dtype != b.dtype)):
         raise TypeError("bias_residual: channels-last device tensors of one shape/dtype required")
     if b.dtype not in (torch.float32, torch.bfloat16) or bias.dtype != b.dtype or bias.numel() != b.shape[1]:
         raise TypeError("bias_residual: unsupported dtype / bias shape")
     out = torch.empty_like(b)
     Bn, C, H, W = b.shape
+    if stats_groups and C % stats_groups == 0 and stats_groups <= 64:
+        # also accumulate the GroupNorm statistics of the result: the GroupNorm that reads it next skips its statistics pass
+        # (group_norm() picks them up from the tensor; they describe exactly this storage, so never modify it in place)
+        stats = torch.empty(Bn * stats_groups * 2, dtype=torch.float64, device=b.device)
+        check(lib().xm3d_bias_residual_stats_nhwc(_ptr(a), _ptr(b), _ptr(bias.contiguous()), 0 if b.dtype == torch.float32 else 1, Bn, C, H * W,
+                                                  int(stats_groups), _ptr(out), _ptr(stats), _stream()), "xm3d_bias_residual_stats_nhwc")
+        out._xm3d_gn_stats = (stats, int(stats_groups), out.data_ptr())
+        return out
     check(lib().xm3d_bias_residual_nhwc(_ptr(a), _ptr(b), _ptr(bias.contiguous()), 0 if b.dtype == torch.float32 else 1, Bn * H * W, C,
                                         _ptr(out), _stream()), "xm3d_bias_residual_nhwc")
     return out

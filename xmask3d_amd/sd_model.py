@@ -51,10 +51,11 @@ def conv_nobias(conv: nn.Conv2d, x):
 
 
 def bias_residual(skip, h, bias):
-    """skip + h + bias[c] in one pass (skip may be None)"""
+    """skip + h + bias[c] in one pass (skip may be None); the GroupNorm(32) statistics of the result are taken on the way - every
+    consumer of a block output in these nets that normalises it uses 32 groups (group_norm())"""
     from . import ops
 
-    return ops.bias_residual(skip, h, bias.to(h.dtype))
+    return ops.bias_residual(skip, h, bias.to(h.dtype), stats_groups=32)
 
 
 def gn_act(norm: nn.GroupNorm, x, act=ACT_NONE, shift=None, residual=None):
