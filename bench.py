@@ -230,6 +230,8 @@ def main():
     ap.add_argument("--train-steps", type=int, default=4,
                     help="training iterations timed after the inference steps (1 view per GPU, DDP when --gpus > 1), reported under "
                          "\"train\" (fp32 as the reference trains, plus a bf16-frozen-nets run); 0 = skip")
+    ap.add_argument("--train-deadline", type=int, default=300,
+                    help="seconds after which a training leg that has not finished is abandoned (the inference line is printed regardless)")
     ap.add_argument("--fp32-steps", type=int, default=4, help="inference steps of the fp32 configuration reported under \"fp32\" (0 = skip)")
     ap.add_argument("--scene-pool", type=int, default=8,
                     help="distinct seeded scenes the timed loop cycles through (8 = two different 4-scene groups alternate)")
@@ -393,16 +395,41 @@ def main():
         del m32
         torch.cuda.empty_cache()
         log(f"fp32 configuration: {fp32['value']:.2f} scenes/s")
-    train = None
-    if args.train_steps > 0:
-        train = train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log, "fp32")
-        torch.cuda.empty_cache()
-        train["bf16_frozen_nets"] = train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log, "bf16")
-        torch.cuda.empty_cache()
-    if rank != 0:
+    out = None
+
+    def finish(train):
+        """the optional training leg comes LAST and under a deadline: whatever happens in it (a collective that never
+        completes on some fabric, a capture that stalls), the inference line measured above is still printed"""
+        import faulthandler
+        import threading
+
+        def on_timeout():
+            faulthandler.dump_traceback(file=sys.stderr)
+            if rank == 0:
+                out["train"] = None
+                out["train_error"] = f"training leg did not finish within {args.train_deadline} s (python stacks on stderr); inference line unaffected"
+                print(json.dumps(out), flush=True)
+            sys.stderr.flush()
+            os._exit(0)
+
+        timer = None
+        if args.train_steps > 0:
+            timer = threading.Timer(args.train_deadline, on_timeout)
+            timer.daemon = True
+            timer.start()
+            train = train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log, "fp32")
+            torch.cuda.empty_cache()
+            train["bf16_frozen_nets"] = train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log, "bf16")
+            torch.cuda.empty_cache()
+            timer.cancel()
+        if rank == 0:
+            out["train"] = train
+            print(json.dumps(out), flush=True)
         if world > 1:
             dist.destroy_process_group()
-        return
+
+    if rank != 0:
+        return finish(None)
 
     log(f"timed {args.steps} steps in {elapsed:.3f} s")
     n_views = len(sd.views)
@@ -431,7 +458,7 @@ def main():
     roofline_stage = {"bound": "mfma", "achieved": dense_tflop / (dense_ms * 1e-3), "peak": peak, "unit": "TFLOP/s",
                       "frac": dense_tflop / (dense_ms * 1e-3) / peak, "traffic": None, "views_per_forward": vb,
                       "scope": "dense 2D branch per view (SD VAE+UNet, projections, pixel+transformer decoder, mask-CLIP): MIOpen / hipBLASLt "
-                               "kernels + HIP flash attention (AOTriton only for the VAE's d=512 head) + HIP GroupNorm, " + ("HIP graph replay" if not args.no_graph else "eager launches"),
+                               "kernels + HIP flash attention (VAE d=512 head: GEMM + HIP row softmax + GEMM) + HIP GroupNorm / LayerNorm / pointwise kernels, " + ("HIP graph replay" if not args.no_graph else "eager launches"),
                       "ms_per_view": dense_ms, "algorithmic_tflop_per_view": dense_tflop, "sparse3d_ms_per_view": sparse_ms}
 
     cpu_baseline = None
@@ -459,11 +486,9 @@ def main():
                    "layout": "NCHW" if args.nchw else "channels-last (NHWC) frozen nets",
                    "schedule": "eager launches" if args.no_graph else "3 HIP graphs per forward (2 slots), next forward's front software-pipelined on side streams"},
         "roofline": roofline, "roofline_dense_stage": roofline_stage, "roofline_kernels": kernel_rooflines(dev),
-        "cpu_baseline": cpu_baseline, "latency_ms_single_scene": latency_ms, "fp32": fp32, "train": train,
+        "cpu_baseline": cpu_baseline, "latency_ms_single_scene": latency_ms, "fp32": fp32, "train": None,
     }
-    print(json.dumps(out))
-    if world > 1:
-        dist.destroy_process_group()
+    finish(None)
 
 
 if __name__ == "__main__":
