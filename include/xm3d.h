@@ -209,6 +209,35 @@ int xm3d_group_norm_nhwc_apply(const void* x, const void* shift, int32_t shift_b
                                int32_t G, const void* gamma, const void* beta, float eps, int32_t silu, const void* residual, void* y,
                                const double* stats, void* stream);
 
+/* ---- fused ResnetBlock convolution (conv.hip): the GroupNorm(32) -> SiLU -> Conv2d(3x3, pad 1) half of ldm's ResnetBlock /
+ * ResBlock, executed from models/modeling/meta_arch/ldm.py:386-414 (VAE encoder), :425-446 (UNet), :448-490 (VAE decoder)
+ * through `ldm.modules.diffusionmodules.model.ResnetBlock.forward` / `openaimodel.ResBlock._forward` (un-vendored
+ * stable-diffusion-sdkit 2.1.3) -> torch.nn.GroupNorm + torch.nn.Conv2d (cuDNN / MIOpen there).
+ *   out = conv3x3( SiLU( GroupNorm(x) ) ) + bias (+ residual)                      bf16 NHWC in / f32 accumulate / bf16 NHWC out
+ * in ONE launch on the matrix cores: the normalisation is applied while the input halo tile is staged in LDS (statistics come
+ * in as f64 moments), bias / per-sample embedding term / skip connection are added in the epilogue, and the moments of `out`
+ * for the NEXT GroupNorm are accumulated there as well.
+ *   xm3d_conv3x3_cout_tile(cout)  -> output-channel tile the kernel uses for `cout` (256 or 128; 0 = unsupported)
+ *   xm3d_conv3x3_pack_weight      : w_ohwi (cout, 3, 3, cin) bf16 (= Conv2d.weight.permute(0,2,3,1)) -> packed (same byte count):
+ *                                   per (cout tile, 64-channel chunk, tap) one contiguous LDS image, rows XOR-swizzled
+ *   xm3d_conv3x3_nhwc             : x (B, H>>upsample, W>>upsample, cin) bf16; out / residual (B, H, W, cout) bf16.
+ *       gn_stats (B, groups, 2) f64 sum / sum of squares of x over each (sample, group), gamma / beta (cin) f32, act = 1 (SiLU);
+ *       gn_stats NULL (act 0): plain convolution of x; upsample = 1 (plain only): x is first nearest-upsampled 2x (ldm Upsample).
+ *       bias (cout) f32 with bias_bstride 0, or (B, cout) with bias_bstride = cout (conv bias + timestep-embedding term), or NULL.
+ *       stats_out (B, groups_out, 2) f64 or NULL: += moments of the bf16 values stored to out (caller zeroes it).
+ *   Constraints: H % 8 == 0, W % 32 == 0, cin % 64 == 0, cout % cout_tile == 0, cin / groups >= 4, (cout / groups_out) % 4 == 0.
+ *   Launched on `stream`, no host synchronisation, no workspace. */
+int xm3d_conv3x3_cout_tile(int32_t cout);
+int xm3d_conv3x3_pack_weight(const void* w_ohwi, int32_t cout, int32_t cin, int32_t cout_tile, void* packed, void* stream);
+int xm3d_conv3x3_nhwc(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,
+                      const double* gn_stats, const float* gamma, const float* beta, float eps, int32_t groups, int32_t act,
+                      const float* bias, int32_t bias_bstride, const void* residual, void* out, double* stats_out,
+                      int32_t groups_out, int32_t upsample, void* stream);
+/* GroupNorm moments alone, in the layout the calls above take: stats (B*G*2) f64 <- (sum, sum of squares) of x (+ shift) per
+ * (sample, group); x (B, H*W, C) channels-last, dtype 0 = f32 / 1 = bf16; stats is zeroed here. */
+int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,
+                               int32_t G, double* stats, void* stream);
+
 /* ---- pointwise fusions around the frozen nets' convolutions / GEMMs (channels-last, dtype 0 = f32, 1 = bf16) ----
  * out = a + b + bias[c] over (pixels, C) NHWC tensors; a may be NULL (out = b + bias).  Replaces the separate broadcast
  * bias kernel PyTorch-ROCm appends to every MIOpen convolution plus the residual add (ldm ResnetBlock.forward `x + h`). */

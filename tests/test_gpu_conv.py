@@ -1,0 +1,118 @@
+"""GPU parity of the fused GroupNorm -> SiLU -> conv3x3 (+ bias, + residual, + output moments) kernel (xm3d_conv3x3_nhwc,
+csrc/conv.hip) through the C ABI.
+
+References, all computed by torch in f32 on the same device from the same bf16 inputs:
+  * exact: small-integer activations and sparse {-1,0,1} weights (every product and partial sum is exact in bf16 / f32), plain
+    convolution mode, asymmetric random data - any indexing / layout / tap-order slip changes integers, so the comparison is
+    bit-exact against F.conv2d;
+  * fused: F.conv2d(bf16(silu(F.group_norm(x))), w) + bias + residual.  bf16 output: bound 1e-2 of max|out| (output rounding
+    2^-9 relative plus single-ulp differences of the bf16-rounded normalised operand; measured ~3e-3);
+  * moments of the stored output against sums over the returned tensor.
+The reference applies this chain as torch.nn.GroupNorm / SiLU / Conv2d inside ldm's ResnetBlock (stable-diffusion-sdkit, absent
+here): numerics of that package are unpinned, the arithmetic definition of the three ops is torch's."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(t):
+    return t.contiguous(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,ups", [(1, 64, 128, 8, 32, False), (2, 128, 256, 16, 64, False), (1, 192, 128, 24, 32, False),
+                                                (2, 64, 256, 16, 64, True), (1, 128, 512, 8, 96, False), (1, 64, 128, 16, 32, True)])
+def test_conv3x3_plain_is_exact_on_integer_data(dev, B, cin, cout, H, W, ups):
+    from xmask3d_amd import ops
+
+    g = torch.Generator().manual_seed(cin * 7 + cout + H + W)
+    hi, wi = (H // 2, W // 2) if ups else (H, W)
+    x = torch.randint(-2, 3, (B, cin, hi, wi), generator=g).float()
+    w = torch.randint(-1, 2, (cout, cin, 3, 3), generator=g).float() * (torch.rand(cout, cin, 3, 3, generator=g) < 0.06).float()
+    bias = torch.randint(-3, 4, (cout,), generator=g).float()
+    xd = _nhwc(x.to(dev, torch.bfloat16))
+    packed, tile = ops.conv3x3_pack_weight(w.to(dev))
+    out = ops.conv3x3(xd, packed, cout, tile, bias=bias.to(dev), upsample=ups)
+    xin = x.to(dev)
+    if ups:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    ref = F.conv2d(xin, w.to(dev), bias.to(dev), padding=1)
+    assert ref.abs().max().item() < 256  # exactly representable in bf16
+    assert out.shape == ref.shape and out.dtype == torch.bfloat16 and out.is_contiguous(memory_format=torch.channels_last)
+    assert torch.equal(out.float(), ref), (out.float() - ref).abs().max().item()
+
+
+@pytest.mark.parametrize("B,cin,cout,H,W,res,per_sample_bias", [(2, 128, 128, 16, 64, True, False), (1, 256, 256, 8, 32, False, True),
+                                                                (2, 128, 256, 16, 32, False, False), (1, 512, 512, 8, 64, True, True),
+                                                                (3, 320, 640, 8, 32, False, True), (1, 128, 128, 40, 32, True, False)])
+def test_conv3x3_groupnorm_silu_matches_torch(dev, B, cin, cout, H, W, res, per_sample_bias):
+    from xmask3d_amd import ops
+
+    g = torch.Generator().manual_seed(cin + cout * 3 + H)
+    G = 32
+    x = _nhwc((torch.randn(B, cin, H, W, generator=g) * 1.7 + 0.3 * torch.randn(1, cin, 1, 1, generator=g)).to(dev, torch.bfloat16))
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev, torch.bfloat16)
+    gamma = (1 + 0.2 * torch.randn(cin, generator=g)).to(dev)
+    beta = (0.2 * torch.randn(cin, generator=g)).to(dev)
+    bias = (0.3 * torch.randn((B, cout) if per_sample_bias else (cout,), generator=g)).to(dev)
+    residual = _nhwc(torch.randn(B, cout, H, W, generator=g).to(dev, torch.bfloat16)) if res else None
+    eps = 1e-6
+    packed, tile = ops.conv3x3_pack_weight(w)
+    stats = ops.gn_stats_of(x, G)
+    gs = 32 if (cout // 32) % 4 == 0 else None
+    out = ops.conv3x3(x, packed, cout, tile, bias=bias, gn=(stats, gamma, beta, eps, G), residual=residual, stats_groups=gs)
+
+    xn = F.silu(F.group_norm(x.float(), G, gamma, beta, eps)).to(torch.bfloat16).float()
+    ref = F.conv2d(xn, w.float(), None, padding=1) + bias.view(-1 if per_sample_bias else 1, cout, 1, 1)
+    if res:
+        ref = ref + residual.float()
+    err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-2, err
+    if gs:
+        st = ops.gn_stats_of(out, gs).view(B, gs, 2)
+        o = out.float().view(B, gs, cout // gs, H * W)
+        want = torch.stack([o.sum((2, 3)), (o * o).sum((2, 3))], -1).double()
+        rel = ((st - want).abs() / (want.abs() + 1.0)).max().item()
+        assert rel < 1e-4, rel
+
+
+def test_conv3x3_chain_is_a_resblock(dev):
+    """two fused convolutions = one VAE ResnetBlock (norm1-silu-conv1-norm2-silu-conv2 + x), the second GroupNorm reading the
+    moments the first convolution's epilogue accumulated"""
+    from xmask3d_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    B, C, H, W, G = 2, 128, 16, 64, 32
+    x = _nhwc(torch.randn(B, C, H, W, generator=g).to(dev, torch.bfloat16))
+    w1, w2 = ((torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(dev, torch.bfloat16) for _ in range(2))
+    g1, b1, g2, b2 = ((1 + 0.1 * torch.randn(C, generator=g)).to(dev) for _ in range(4))
+    c1, c2 = (0.1 * torch.randn(C, generator=g)).to(dev), (0.1 * torch.randn(C, generator=g)).to(dev)
+    p1, t1 = ops.conv3x3_pack_weight(w1)
+    p2, t2 = ops.conv3x3_pack_weight(w2)
+    h = ops.conv3x3(x, p1, C, t1, bias=c1, gn=(ops.gn_stats_of(x, G), g1, b1, 1e-6, G), stats_groups=G)
+    assert getattr(h, "_xm3d_gn_stats", None) is not None
+    out = ops.conv3x3(h, p2, C, t2, bias=c2, gn=(ops.gn_stats_of(h, G), g2, b2, 1e-6, G), residual=x, stats_groups=G)
+
+    hr = F.conv2d(F.silu(F.group_norm(x.float(), G, g1, b1, 1e-6)).to(torch.bfloat16).float(), w1.float(), c1, padding=1).to(torch.bfloat16).float()
+    ref = x.float() + F.conv2d(F.silu(F.group_norm(hr, G, g2, b2, 1e-6)).to(torch.bfloat16).float(), w2.float(), c2, padding=1)
+    err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1.5e-2, err
+
+
+def test_conv3x3_rejects_what_it_cannot_run(dev):
+    from xmask3d_amd import ops
+    from xmask3d_amd._lib import Xm3dError
+
+    x = _nhwc(torch.zeros(1, 64, 8, 16, device=dev, dtype=torch.bfloat16))  # W % 32 != 0
+    assert not ops.conv3x3_supported(x, 128)
+    with pytest.raises(TypeError):
+        ops.conv3x3_pack_weight(torch.zeros(96, 64, 3, 3, device=dev))  # cout % 128 != 0
+    x = _nhwc(torch.zeros(1, 64, 8, 32, device=dev, dtype=torch.bfloat16))
+    packed, tile = ops.conv3x3_pack_weight(torch.zeros(128, 64, 3, 3, device=dev))
+    with pytest.raises(Xm3dError):  # an activation without statistics
+        from xmask3d_amd.ops import _ptr, _stream, lib
+        from xmask3d_amd._lib import check
+        out = torch.empty_like(x)
+        check(lib().xm3d_conv3x3_nhwc(_ptr(x), 1, 8, 32, 64, _ptr(packed), 128, tile, None, None, None, 0.0, 0, 1, None, 0, None, _ptr(out), None, 0, 0,
+                                      _stream()), "xm3d_conv3x3_nhwc")

@@ -11,7 +11,7 @@ import os
 import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libxm3d_hip.so")
+LIB_PATH = os.environ.get("XM3D_LIB") or os.path.join(_HERE, "libxm3d_hip.so")  # XM3D_LIB: diagnostic builds (tools/conv_ablate.sh)
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "xm3d.h")
 
 c_i32, c_i64, c_sz, c_vp = ctypes.c_int32, ctypes.c_int64, ctypes.c_size_t, ctypes.c_void_p
@@ -58,6 +58,11 @@ _SIGS = {
     "xm3d_bias_residual_stats_nhwc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp]),
     "xm3d_group_norm_nhwc_apply": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp,
                                                 c_vp, c_vp]),
+    "xm3d_conv3x3_cout_tile": (ctypes.c_int, [c_i32]),
+    "xm3d_conv3x3_pack_weight": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
+    "xm3d_conv3x3_nhwc": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, ctypes.c_float, c_i32, c_i32,
+                                         c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_vp]),
+    "xm3d_group_norm_nhwc_stats": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_bias_residual_nhwc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "xm3d_attn_mask_bias": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "xm3d_attention_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,

@@ -391,6 +391,38 @@ extern "C" int xm3d_group_norm(const void* x, int32_t dtype, int64_t B, int32_t 
     return gn_launch<__hip_bfloat16>(x, B, C, hw, G, gamma, beta, eps, silu, y, stats_ws, s);
 }
 
+template <typename T>
+static int gn_stats_only_nhwc(const void* x, const void* shift, int shift_bstride, int64_t B, int C, int hw, int G, double* stats, hipStream_t s) {
+    const int cg = C / G;
+    const int nstat = int(B) * G * 2;
+    hipLaunchKernelGGL(k_gn_zero, dim3((nstat + 255) / 256), dim3(256), 0, s, stats, nstat);
+    const int vpp = C / VecIO<T>::N;
+    const int lanes = vpp < 256 ? 256 / vpp : 1;
+    int64_t pix = (B * int64_t(hw) + 1023) / 1024;
+    if (pix < lanes) pix = lanes;
+    if (pix > 256) pix = 256;
+    if (pix > hw) pix = hw;
+    const int slabs = int((hw + pix - 1) / pix);
+    hipLaunchKernelGGL(k_gn_stats_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift), shift_bstride, hw, C, cg, G, slabs, int(pix), stats);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+extern "C" int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,
+                                          int32_t G, double* stats, void* stream) {
+    XM3D_REQUIRE(B >= 0 && C >= 1 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "group_norm_nhwc_stats: bad shape B=%lld C=%d hw=%d G=%d",
+                 (long long)B, C, hw, G);
+    XM3D_REQUIRE(dtype == 0 || dtype == 1, "group_norm_nhwc_stats: dtype must be 0 (f32) or 1 (bf16)");
+    if (B == 0) return XM3D_OK;
+    XM3D_REQUIRE(x && stats, "group_norm_nhwc_stats: null pointer");
+    XM3D_REQUIRE(C % (dtype == 0 ? 4 : 8) == 0, "group_norm_nhwc_stats: C=%d must be a multiple of %d", C, dtype == 0 ? 4 : 8);
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0, "group_norm_nhwc_stats: tensors must be 16-byte aligned");
+    XM3D_REQUIRE(shift_bstride == 0 || shift_bstride == C, "group_norm_nhwc_stats: shift_bstride must be 0 (shared) or C (per sample)");
+    hipStream_t s = as_stream(stream);
+    if (dtype == 0) return gn_stats_only_nhwc<float>(x, shift, shift_bstride, B, C, hw, G, stats, s);
+    return gn_stats_only_nhwc<__hip_bfloat16>(x, shift, shift_bstride, B, C, hw, G, stats, s);
+}
+
 extern "C" int xm3d_group_norm_nhwc_res(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C,
                                         int32_t hw, int32_t G, const void* gamma, const void* beta, float eps, int32_t silu,
                                         const void* residual, void* y, double* stats_ws, void* stream) {

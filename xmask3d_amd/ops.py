@@ -463,6 +463,82 @@ def bias_residual(a, b, bias, stats_groups=None):
     return out
 
 
+# ---------------------------------------------------------------- fused GroupNorm -> SiLU -> conv3x3 (conv.hip)
+def gn_stats_of(x, num_groups=32):
+    """(B*G*2,) f64 GroupNorm moments (sum, sum of squares per (sample, group)) of a channels-last tensor: taken from the tensor
+    if the kernel that produced it left them there (conv3x3 / bias_residual epilogues), else by one statistics pass."""
+    pre = getattr(x, "_xm3d_gn_stats", None)
+    if pre is not None and pre[1] == num_groups and pre[2] == x.data_ptr():
+        return pre[0]
+    if not is_nhwc(x) or x.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError("gn_stats_of: channels-last f32/bf16 device tensor required")
+    B, C, H, W = x.shape
+    stats = torch.empty(B * num_groups * 2, dtype=torch.float64, device=x.device)
+    check(lib().xm3d_group_norm_nhwc_stats(_ptr(x), None, 0, 0 if x.dtype == torch.float32 else 1, B, C, H * W, num_groups, _ptr(stats), _stream()),
+          "xm3d_group_norm_nhwc_stats")
+    return stats
+
+
+def conv3x3_supported(x, cout, upsample=False):
+    """shapes xm3d_conv3x3_nhwc takes: channels-last bf16, output H % 8 == 0, W % 32 == 0, cin % 64 == 0, cout % 128 == 0"""
+    if not (is_nhwc(x) and x.dtype == torch.bfloat16):
+        return False
+    _, cin, H, W = x.shape
+    if upsample:
+        H, W = 2 * H, 2 * W
+    return H % 8 == 0 and W % 32 == 0 and cin % 64 == 0 and cout % 128 == 0
+
+
+def conv3x3_pack_weight(weight):
+    """Conv2d weight (cout, cin, 3, 3), any float dtype / memory format -> (packed bf16 tensor, cout tile)"""
+    cout, cin = weight.shape[0], weight.shape[1]
+    tile = lib().xm3d_conv3x3_cout_tile(cout)
+    if tile == 0 or cin % 64 != 0 or tuple(weight.shape[2:]) != (3, 3):
+        raise TypeError(f"conv3x3_pack_weight: unsupported weight shape {tuple(weight.shape)}")
+    w = weight.detach().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()  # OHWI
+    packed = torch.empty_like(w)
+    check(lib().xm3d_conv3x3_pack_weight(_ptr(w), cout, cin, tile, _ptr(packed), _stream()), "xm3d_conv3x3_pack_weight")
+    return packed, tile
+
+
+def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_groups=None, upsample=False):
+    """out = conv3x3(SiLU(GroupNorm(x))) + bias (+ residual), channels-last bf16 (B, C, H, W) in and out.
+    packed, tile: conv3x3_pack_weight(weight).  gn: None (plain convolution) or (stats f64 (B*G*2), gamma f32 (cin), beta f32 (cin),
+    eps, G).  bias: None, (cout,) or (B, cout) f32.  residual: tensor like the output.  stats_groups: G of the GroupNorm that reads
+    the result next - its moments are accumulated in the epilogue and attached to the returned tensor (gn_stats_of picks them up).
+    upsample: x is nearest-upsampled 2x first (plain convolution only)."""
+    if not conv3x3_supported(x, cout, upsample):
+        raise TypeError(f"conv3x3: unsupported input {tuple(x.shape)} {x.dtype} (channels-last bf16, H % 8, W % 32, cin % 64, cout % 128)")
+    B, cin, H, W = x.shape
+    if upsample:
+        H, W = 2 * H, 2 * W
+    out = torch.empty((B, cout, H, W), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    bstride = 0
+    if bias is not None:
+        if bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() not in (cout, B * cout):
+            raise TypeError("conv3x3: bias must be a contiguous f32 (cout,) or (B, cout) tensor")
+        bstride = cout if (bias.numel() == B * cout and B > 1) else 0
+    if residual is not None and not (is_nhwc(residual) and residual.dtype == torch.bfloat16 and residual.shape == out.shape):
+        raise TypeError("conv3x3: residual must be a channels-last bf16 tensor of the output's shape")
+    stats_in = gamma = beta = None
+    eps, G, act = 0.0, 0, 0
+    if gn is not None:
+        stats_in, gamma, beta, eps, G = gn
+        if stats_in.dtype != torch.float64 or stats_in.numel() != B * G * 2 or gamma.dtype != torch.float32 or beta.dtype != torch.float32 \
+                or gamma.numel() != cin or beta.numel() != cin:
+            raise TypeError("conv3x3: gn = (f64 moments (B*G*2), f32 gamma (cin), f32 beta (cin), eps, G)")
+        act = 1
+    stats_out = None
+    if stats_groups:
+        stats_out = torch.zeros(B * stats_groups * 2, dtype=torch.float64, device=x.device)
+    check(lib().xm3d_conv3x3_nhwc(_ptr(x), B, H, W, cin, _ptr(packed), cout, tile, _ptr(stats_in), _ptr(gamma), _ptr(beta), float(eps), int(G), act,
+                                  _ptr(bias), bstride, _ptr(residual), _ptr(out), _ptr(stats_out), int(stats_groups or 0), int(bool(upsample)),
+                                  _stream()), "xm3d_conv3x3_nhwc")
+    if stats_out is not None:
+        out._xm3d_gn_stats = (stats_out, int(stats_groups), out.data_ptr())
+    return out
+
+
 def attn_mask_bias(logits, size, out_dtype):
     """mask logits (B,Q,H,W) f32/bf16 -> additive attention bias (B,Q,h*w) of dtype out_dtype (0 / -inf), see xm3d.h"""
     if not logits.is_cuda or logits.dtype not in (torch.float32, torch.bfloat16) or out_dtype not in (torch.float32, torch.bfloat16):
