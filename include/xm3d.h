@@ -219,20 +219,25 @@ int xm3d_group_norm_nhwc_apply(const void* x, const void* shift, int32_t shift_b
  * for the NEXT GroupNorm are accumulated there as well.
  *   xm3d_conv3x3_cout_tile(cout)  -> output-channel tile the kernel uses for `cout` (256 or 128; 0 = unsupported)
  *   xm3d_conv3x3_pack_weight      : w_ohwi (cout, 3, 3, cin) bf16 (= Conv2d.weight.permute(0,2,3,1)) -> packed (same byte count):
- *                                   per (cout tile, 64-channel chunk, tap) one contiguous LDS image, rows XOR-swizzled
+ *                                   per (cout tile, 32-row block) one contiguous stream of MFMA A fragments, 1 KiB per k-step
  *   xm3d_conv3x3_nhwc             : x (B, H>>upsample, W>>upsample, cin) bf16; out / residual (B, H, W, cout) bf16.
  *       gn_stats (B, groups, 2) f64 sum / sum of squares of x over each (sample, group), gamma / beta (cin) f32, act = 1 (SiLU);
+ *       in_shift (cin) f32 with in_shift_bstride 0, or (B, cin) with in_shift_bstride = cin, or NULL: the GroupNorm input is x + in_shift
+ *       (a convolution bias the producer of x left to its consumer) and gn_stats are the moments of that sum.
  *       gn_stats NULL (act 0): plain convolution of x; upsample = 1 (plain only): x is first nearest-upsampled 2x (ldm Upsample).
  *       bias (cout) f32 with bias_bstride 0, or (B, cout) with bias_bstride = cout (conv bias + timestep-embedding term), or NULL.
  *       stats_out (B, groups_out, 2) f64 or NULL: += moments of the bf16 values stored to out (caller zeroes it).
- *   Constraints: H % 8 == 0, W % 32 == 0, cin % 64 == 0, cout % cout_tile == 0, cin / groups >= 4, (cout / groups_out) % 4 == 0.
- *   Launched on `stream`, no host synchronisation, no workspace. */
+ *       ws: xm3d_conv3x3_ws_bytes(B, cin) bytes of device scratch (the per-(image, channel) affine derived from the moments by a
+ *       small kernel in front of the convolution); may be NULL without GroupNorm.
+ *   Constraints: H % 8 == 0, W % 32 == 0, cin % 64 == 0, cout % cout_tile == 0, (cout / groups_out) % 4 == 0, 16-byte aligned tensors.
+ *   Launched on `stream`, no host synchronisation. */
 int xm3d_conv3x3_cout_tile(int32_t cout);
 int xm3d_conv3x3_pack_weight(const void* w_ohwi, int32_t cout, int32_t cin, int32_t cout_tile, void* packed, void* stream);
+int64_t xm3d_conv3x3_ws_bytes(int64_t B, int32_t cin);
 int xm3d_conv3x3_nhwc(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,
-                      const double* gn_stats, const float* gamma, const float* beta, float eps, int32_t groups, int32_t act,
-                      const float* bias, int32_t bias_bstride, const void* residual, void* out, double* stats_out,
-                      int32_t groups_out, int32_t upsample, void* stream);
+                      const double* gn_stats, const float* gamma, const float* beta, const float* in_shift, int32_t in_shift_bstride,
+                      float eps, int32_t groups, int32_t act, const float* bias, int32_t bias_bstride, const void* residual, void* out, double* stats_out,
+                      int32_t groups_out, int32_t upsample, void* ws, void* stream);
 /* GroupNorm moments alone, in the layout the calls above take: stats (B*G*2) f64 <- (sum, sum of squares) of x (+ shift) per
  * (sample, group); x (B, H*W, C) channels-last, dtype 0 = f32 / 1 = bf16; stats is zeroed here. */
 int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,

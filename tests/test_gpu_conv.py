@@ -45,7 +45,7 @@ def test_conv3x3_plain_is_exact_on_integer_data(dev, B, cin, cout, H, W, ups):
 
 @pytest.mark.parametrize("B,cin,cout,H,W,res,per_sample_bias", [(2, 128, 128, 16, 64, True, False), (1, 256, 256, 8, 32, False, True),
                                                                 (2, 128, 256, 16, 32, False, False), (1, 512, 512, 8, 64, True, True),
-                                                                (3, 320, 640, 8, 32, False, True), (1, 128, 128, 40, 32, True, False)])
+                                                                (3, 320, 640, 8, 32, False, True), (1, 128, 128, 40, 32, True, False), (1, 64, 128, 8, 32, False, False)])
 def test_conv3x3_groupnorm_silu_matches_torch(dev, B, cin, cout, H, W, res, per_sample_bias):
     from xmask3d_amd import ops
 
@@ -114,5 +114,58 @@ def test_conv3x3_rejects_what_it_cannot_run(dev):
         from xmask3d_amd.ops import _ptr, _stream, lib
         from xmask3d_amd._lib import check
         out = torch.empty_like(x)
-        check(lib().xm3d_conv3x3_nhwc(_ptr(x), 1, 8, 32, 64, _ptr(packed), 128, tile, None, None, None, 0.0, 0, 1, None, 0, None, _ptr(out), None, 0, 0,
-                                      _stream()), "xm3d_conv3x3_nhwc")
+        check(lib().xm3d_conv3x3_nhwc(_ptr(x), 1, 8, 32, 64, _ptr(packed), 128, tile, None, None, None, None, 0, 0.0, 0, 1, None, 0, None, _ptr(out), None, 0, 0,
+                                      None, _stream()), "xm3d_conv3x3_nhwc")
+
+
+def _module_pair(mod_fn, dev):
+    """the same frozen module twice: bf16 channels-last (HIP convolution path) and f32 (torch ops)"""
+    torch.manual_seed(5)
+    ref = mod_fn().to(dev).eval()
+    for prm in ref.parameters():
+        prm.data.copy_(prm.data.to(torch.bfloat16).float())  # both copies hold bf16-representable weights
+    fast = mod_fn().to(dev).eval()
+    fast.load_state_dict(ref.state_dict())
+    return ref, fast.to(torch.bfloat16).to(memory_format=torch.channels_last)
+
+
+@pytest.mark.parametrize("cin,cout,H,W,with_pend", [(128, 128, 16, 64, True), (128, 256, 16, 32, True), (256, 256, 8, 64, False), (512, 512, 8, 32, False)])
+def test_vae_resblock_on_hip_convolutions(dev, cin, cout, H, W, with_pend):
+    from xmask3d_amd import sd_model
+
+    ref, fast = _module_pair(lambda: sd_model.VaeResBlock(cin, cout), dev)
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(2, cin, H, W, generator=g).to(dev, torch.bfloat16)
+    pend = (0.3 * torch.randn(cin, generator=g)).to(dev, torch.bfloat16) if with_pend else None
+    with torch.no_grad():
+        xf = _nhwc(x)
+        assert sd_model.fused_conv_ok(xf, fast.conv1)
+        out = fast(xf, pend=pend)
+        want = ref(x.float(), pend=None if pend is None else pend.float())
+    assert getattr(out, "_xm3d_gn_stats", None) is not None  # moments for the next block's norm1
+    err = (out.float() - want).abs().max().item() / want.abs().max().item()
+    assert err < 2e-2, err
+
+
+def test_unet_resblock_and_upsample_on_hip_convolutions(dev):
+    from xmask3d_amd import sd_model
+
+    ref, fast = _module_pair(lambda: sd_model.UNetResBlock(1280, 1280, 640), dev)
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(2, 1280, 32, 32, generator=g).to(dev, torch.bfloat16)
+    emb = torch.randn(2, 1280, generator=g).to(dev, torch.bfloat16)
+    with torch.no_grad():
+        assert sd_model.fused_conv_ok(_nhwc(x), fast.in_layers[2])
+        out = fast(_nhwc(x), emb)
+        want = ref(x.float(), emb.float())
+    err = (out.float() - want).abs().max().item() / want.abs().max().item()
+    assert err < 2e-2, err
+
+    ref, fast = _module_pair(lambda: sd_model.VaeUpsample(256), dev)
+    x = torch.randn(2, 256, 16, 32, generator=g).to(dev, torch.bfloat16)
+    with torch.no_grad():
+        out, pend = fast(_nhwc(x), defer_bias=True)
+        want = ref(x.float())
+    assert pend is None and tuple(out.shape) == (2, 256, 32, 64)
+    err = (out.float() - want).abs().max().item() / want.abs().max().item()
+    assert err < 1e-2, err

@@ -6,24 +6,27 @@
 // This is the ResnetBlock body of ldm's VAE / UNet (GroupNorm(32) -> SiLU -> Conv2d(3x3), twice, + skip), reached from
 // /root/reference/models/modeling/meta_arch/ldm.py:386-414 (VAE encoder), :425-446 (UNet), :448-490 (VAE decoder): the FLOP
 // majority of the whole scene.  It replaces, per convolution, {GroupNorm statistics pass, GroupNorm apply + SiLU pass, library
-// implicit-GEMM convolution, bias / residual pass} by ONE launch that reads x once (+ 27 % halo) and writes out once.
+// implicit-GEMM convolution, bias / residual pass} by ONE launch that reads x once (+ 33 % halo) and writes out once.
 //
 // Decomposition (one workgroup = 8 waves = one 8 x 32 pixel tile of one image x CT output channels):
-//   * K loop = input-channel chunks of 64 (outer) x the 9 filter taps (inner).  Per chunk the (8+2) x (32+2) HALO tile of the
-//     input is staged ONCE in LDS - raw bf16 from global memory into registers, normalised with the per-(image, channel)
-//     affine derived from the f64 GroupNorm moments, SiLU, rounded to bf16, written with a 144-byte pixel stride - and all 9
-//     taps read it with the same per-lane address plus an immediate: a tap is a shift of the pixel index, and the padded
-//     stride makes the 32-pixel fragment reads bank-conflict free at ANY shift.  The normalisation work is therefore done once
-//     per element (x 1.33 halo), not 9 times, and the activation operand costs 1/9 of an im2col-style staging.
-//   * per (chunk, tap) stage the CT x 64 weight tile arrives by LDS-DMA (global_load_lds_dwordx4) from a pre-packed image
-//     (xm3d_conv3x3_pack_weight: stage-major, rows XOR-swizzled so that the fragment reads are conflict free); two weight
-//     buffers, the DMA of stage s+1 is issued at the top of stage s and has a whole stage (>= 1024 MFMA cycles) to land;
-//     the halo tile of the NEXT chunk is staged during taps 0..5 of the current one (one 16-byte piece per thread and tap),
-//     so the normalisation VALU work runs beside the MFMAs of the other wave on the SIMD.  One barrier per stage.
+//   * K loop = input-channel chunks of 64 (outer) x the 9 filter taps (inner) x 4 MFMA k-steps of 16 channels.
+//   * ACTIVATIONS: per chunk the (8+2) x (32+2) HALO tile of the input is staged ONCE in LDS - raw bf16 from global memory into
+//     registers, normalised with the per-(image, channel) affine derived from the f64 GroupNorm moments, SiLU, rounded to bf16,
+//     written with a 144-byte pixel stride - and all 9 taps read it with the same per-lane address plus an immediate: a tap is
+//     a shift of the pixel index, and the padded stride makes the 32-pixel fragment reads (ds_read_b128) bank-conflict free at
+//     ANY shift.  The normalisation is therefore done once per element (x 1.33 halo), not 9 times, and the activation operand
+//     costs 1/9 of an im2col-style staging.  Two halo buffers: the tile of chunk c+1 is staged during the taps of chunk c (one
+//     16-byte piece per thread and stage, requested one stage before it is normalised), ONE workgroup barrier per chunk.
+//   * WEIGHTS never touch LDS: every wave owns 32 output channels (rows) of the tile and streams exactly its own MFMA A
+//     fragments from a pre-packed, fragment-ordered image (xm3d_conv3x3_pack_weight) through L2 straight into registers, one
+//     global_load_dwordx4 per k-step, six k-steps ahead (register ring).  No wave ever waits for another wave's loads, so there
+//     is no per-stage barrier and no lockstep: the two waves of a SIMD drift apart and one's normalisation VALU work and
+//     fragment reads run under the other's MFMAs.  (The first version shared a CT x 64 weight tile per stage through LDS-DMA
+//     with a barrier per stage: 47 % of the time the matrix pipe sat idle behind {barrier, DMA issue, first fragment reads}.)
 //   * MFMA v_mfma_f32_32x32x16_bf16 with the WEIGHTS as A operand (rows = output channels) and the pixels as B operand:
 //     the accumulator has the pixel on the lane and 4 consecutive output channels per register quad = 8-byte bf16 stores,
 //     and the GroupNorm statistics of the result are in-lane sums + one 32-lane reduction per channel quad.
-//   * waves 2 (output channels) x 4 (pixel rows): wave tile (CT/2) channels x 64 pixels.
+//   * wave tile: CT = 256: 32 channels x all 256 pixels (8 accumulator tiles); CT = 128: 32 channels x 128 pixels (waves 4 x 2).
 // Bound: MFMA (bf16).  Algorithmic FLOP = 2 * B*H*W * 9*Cin * Cout; bytes = B*H*W*(Cin + Cout [+ Cout residual])*2 + weights.
 #include "common.h"
 
@@ -32,6 +35,7 @@ namespace xm3d {
 typedef float cv_f32x16 __attribute__((ext_vector_type(16)));
 typedef __bf16 cv_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 cv_bf16x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 cv_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned cv_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int CV_TW = 32, CV_TH = 8;                 // output pixel tile (one image)
@@ -43,51 +47,45 @@ constexpr int CV_KC = 64;                            // input channels per chunk
 constexpr int CV_ROUNDS = (CV_HPIX * 8 + 511) / 512; // 16-byte pieces per thread and chunk (6; the last round is partial)
 constexpr float CV_LOG2E = 1.4426950408889634f;
 #ifndef CV_ABL
-#define CV_ABL 0  // timing-only ablations (tools/conv_ablate.sh): 1 no weight DMA, 2 no MFMA, 4 no fragment reads, 8 no stage barrier, 16 no halo staging
+#define CV_ABL 0  // timing-only ablations (tools/conv_ablate.sh): 1 no weight ring refill, 2 no MFMA, 4 no fragment reads, 8 no chunk barrier, 16 no halo staging
+#endif
+#ifndef CV_WRING
+#define CV_WRING 6  // weight fragments in flight per wave (k-steps); must divide 36
+#endif
+#ifndef CV_WRITE_KS
+#define CV_WRITE_KS 1  // k-step of a stage in which the halo piece requested one stage earlier is normalised and stored
 #endif
 
 struct ConvArgs {
     const __bf16* x;          // (B, H>>ups, W>>ups, cin)
     const __bf16* wp;         // packed weights (xm3d_conv3x3_pack_weight)
-    const double* gn_stats;   // (B, groups_in, 2) sum / sum of squares of x, or null
-    const float* gamma;       // (cin)
-    const float* beta;        // (cin)
+    const float* affine;      // (B, cin / 8, 2, 8) GroupNorm scale / shift per (image, channel), or null (k_gn_affine)
     const float* bias;        // (cout) or (B, cout) with bias_bstride = cout, or null
     const __bf16* residual;   // (B, H, W, cout) or null
     __bf16* out;              // (B, H, W, cout)
     double* stats_out;        // (B, groups_out, 2) accumulated (+=), or null
     int B, H, W, cin, cout;
-    int groups_in, cg_in;
-    double inv_cnt_in;
-    float eps;
     int bias_bstride;
     int groups_out, cg_out;
     int tiles_x, tiles_y, nct;
 };
 
-__device__ __forceinline__ unsigned cv_lds_addr(const void* p) {
-    return static_cast<unsigned>(reinterpret_cast<uintptr_t>(reinterpret_cast<const __attribute__((address_space(3))) char*>(reinterpret_cast<uintptr_t>(p))));
-}
-
-__device__ __forceinline__ void cv_glds16(const void* gsrc, void* lds_wave_base) {
-    __builtin_amdgcn_global_load_lds(reinterpret_cast<const __attribute__((address_space(1))) void*>(reinterpret_cast<uintptr_t>(gsrc)),
-                                     reinterpret_cast<__attribute__((address_space(3))) void*>(static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds_wave_base))),
-                                     16, 0, 0);
-}
-
 // MODE 0: x is the operand as it stands (plain convolution); MODE 2: operand = SiLU(GroupNorm(x)).
 // UPS: x has half the resolution, the operand is its nearest-neighbour 2x upsampling (ldm's Upsample -> conv).
 template <int CT, int MODE, bool UPS>
 __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
-    constexpr int MT = CT / 64;        // 32-channel MFMA row tiles per wave
-    constexpr int BSZ = CT * 128;      // bytes per weight stage
+    constexpr int NT = CT == 256 ? 8 : 4;  // 32-pixel tiles (= rows of the pixel tile) per wave
+    constexpr int NG = NT / 4;             // groups of 4 MFMAs per k-step
+    constexpr int NGRP = 36 * NG;          // groups per chunk
+    constexpr int D = CV_WRING;            // weight ring depth (k-steps in flight)
+    constexpr int ROWB = CV_HW * CV_PSTR;  // bytes per halo row
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    char* const abuf = smem;                 // 2 halo buffers
-    char* const bbuf = smem + 2 * CV_ASZ;    // 2 weight buffers
+    char* const abuf = smem;  // 2 halo buffers, then a 16-byte dump slot
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int w_m = wave >> 2, w_n = wave & 3;
+    const int wb = CT == 256 ? wave : wave >> 1;          // 32-channel row block of the tile owned by this wave
+    const int nbase = CT == 256 ? 0 : 4 * (wave & 1);     // first pixel row of this wave
     const int l31 = lane & 31, h = lane >> 5;
 
     // XCD-aware tile order (speed only): blocks i and i + 8 share an XCD's L2 - give each XCD a contiguous run of tiles
@@ -107,6 +105,13 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
     const int Hi = UPS ? H >> 1 : H, Wi = UPS ? W >> 1 : W;
     const __bf16* const xb = a.x + int64_t(b) * Hi * Wi * cin;
     const int nch = cin / CV_KC;
+    const int nk = nch * 36;  // k-steps
+
+    // ---- weight stream of this wave: 1 KiB (64 lanes x 16 bytes = one A fragment) per k-step, contiguous
+    const char* const wstream = reinterpret_cast<const char*>(a.wp) + (int64_t(ct) * (CT / 32) + wb) * nk * 1024 + lane * 16;
+    cv_bf16x8 wr[D];
+#pragma unroll
+    for (int i = 0; i < D; ++i) wr[i] = *reinterpret_cast<const cv_bf16x8*>(wstream + int64_t(i < nk ? i : nk - 1) * 1024);
 
     // ---- halo staging: thread owns 16-byte piece (pixel prow + 64 r, channels 8 kc .. 8 kc + 7) of every round r
     const int kc = tid & 7, prow = tid >> 3;
@@ -122,170 +127,127 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
     }
     const unsigned a_wr = unsigned(prow) * CV_PSTR + kc * 16;  // + r * 64 * CV_PSTR
 
-    float sc[8], sh[8];  // GroupNorm affine of the chunk being staged: y = x * sc + sh
+    // GroupNorm affine of the chunk being staged, y = x * sc + sh: per-(image, channel) table written by k_gn_affine just before
+    // this launch.  Loaded for the chunk after next in stage 7, when the last piece of the next one has been normalised.
+    float sc[8], sh[8];
+    const float* const aff = MODE != 0 ? a.affine + (int64_t(b) * cin + kc * 8) * 2 : nullptr;
     auto gn_coeffs = [&](int c0) __attribute__((always_inline)) {
         if constexpr (MODE != 0) {
-            const int ch0 = c0 + kc * 8;
-            const int g0 = ch0 / a.cg_in, g1 = (ch0 + 7) / a.cg_in;  // <= 2 groups per 8 channels (cg_in >= 4)
-            const double* st = a.gn_stats + (int64_t(b) * a.groups_in + g0) * 2;
-            const double s0 = st[0], q0 = st[1], s1 = st[(g1 - g0) * 2], q1 = st[(g1 - g0) * 2 + 1];
-            const double m0 = s0 * a.inv_cnt_in, m1 = s1 * a.inv_cnt_in;
-            const float v0 = float(q0 * a.inv_cnt_in - m0 * m0), v1 = float(q1 * a.inv_cnt_in - m1 * m1);
-            const float r0 = rsqrtf(fmaxf(v0, 0.f) + a.eps), r1 = rsqrtf(fmaxf(v1, 0.f) + a.eps);
-            const float fm0 = float(m0), fm1 = float(m1);
-            const int split = (g0 + 1) * a.cg_in - ch0;
-            const float4 ga0 = *reinterpret_cast<const float4*>(a.gamma + ch0), ga1 = *reinterpret_cast<const float4*>(a.gamma + ch0 + 4);
-            const float4 be0 = *reinterpret_cast<const float4*>(a.beta + ch0), be1 = *reinterpret_cast<const float4*>(a.beta + ch0 + 4);
-            const float ga[8] = {ga0.x, ga0.y, ga0.z, ga0.w, ga1.x, ga1.y, ga1.z, ga1.w};
-            const float be[8] = {be0.x, be0.y, be0.z, be0.w, be1.x, be1.y, be1.z, be1.w};
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const float mean = j < split ? fm0 : fm1, rstd = j < split ? r0 : r1;
-                sc[j] = ga[j] * rstd;
-                sh[j] = be[j] - mean * sc[j];
-            }
+            const float4 s0 = *reinterpret_cast<const float4*>(aff + c0 * 2), s1 = *reinterpret_cast<const float4*>(aff + c0 * 2 + 4);
+            const float4 h0 = *reinterpret_cast<const float4*>(aff + c0 * 2 + 8), h1 = *reinterpret_cast<const float4*>(aff + c0 * 2 + 12);
+            sc[0] = s0.x, sc[1] = s0.y, sc[2] = s0.z, sc[3] = s0.w, sc[4] = s1.x, sc[5] = s1.y, sc[6] = s1.z, sc[7] = s1.w;
+            sh[0] = h0.x, sh[1] = h0.y, sh[2] = h0.z, sh[3] = h0.w, sh[4] = h1.x, sh[5] = h1.y, sh[6] = h1.z, sh[7] = h1.w;
         }
     };
-    // branch free (the whole tap loop is one basic block between barriers): a piece outside the image reads the image's first
-    // pixel and is zeroed on the way to LDS; the threads without a piece in the last, partial round write to a dump slot
-    auto a_load = [&](int r, int c0) __attribute__((always_inline)) -> uint4 {
-        return *reinterpret_cast<const uint4*>(xb + (aoff[r] >= 0 ? aoff[r] : kc * 8) + c0);
+    // branch free (a chunk's 36 k-steps are one basic block): a piece outside the image reads the image's first pixel and is
+    // zeroed on the way to LDS; the threads without a piece in the last, partial round write to a dump slot
+    auto a_load = [&](int r, int c0) __attribute__((always_inline)) -> cv_u32x4 {
+        return *reinterpret_cast<const cv_u32x4*>(xb + (aoff[r] >= 0 ? aoff[r] : kc * 8) + c0);
     };
-    // the same load hidden from hipcc's wait bookkeeping (main loop): beside LDS-DMA loads hipcc waits vmcnt(0) at the first use
-    // of an ordinary load - here that would be mid-stage, a few hundred cycles behind the request.  Nothing waits for it
-    // explicitly: the value is first used in the NEXT stage, behind the vmcnt(0) + barrier that ends this one.
-    auto a_load_async = [&](int r, int c0) __attribute__((always_inline)) -> cv_u32x4 {
-        cv_u32x4 v;
-        const __bf16* p = xb + (aoff[r] >= 0 ? aoff[r] : kc * 8) + c0;
-        asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(v) : "v"(p) : "memory");
-        return v;
-    };
-    auto a_write = [&](int r, uint4 raw, char* dst, bool hidden) __attribute__((always_inline)) {
-        uint4 o = raw;
+    // normalise + SiLU channel pair i of a piece in place (two bf16 in -> two bf16 out in the same register)
+    auto a_norm_pair = [&](cv_u32x4& raw, int i) __attribute__((always_inline)) {
         if constexpr (MODE != 0) {
-            const unsigned w[4] = {raw.x, raw.y, raw.z, raw.w};
-            float y[8];
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                y[2 * i] = fmaf(__uint_as_float(w[i] << 16), sc[2 * i], sh[2 * i]);
-                y[2 * i + 1] = fmaf(__uint_as_float(w[i] & 0xFFFF0000u), sc[2 * i + 1], sh[2 * i + 1]);
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) y[i] = y[i] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-CV_LOG2E * y[i]));
-            cv_bf16x8 pk;
-#pragma unroll
-            for (int i = 0; i < 8; ++i) pk[i] = (__bf16)y[i];
-            o = __builtin_bit_cast(uint4, pk);
+            float y0 = fmaf(__uint_as_float(raw[i] << 16), sc[2 * i], sh[2 * i]);
+            float y1 = fmaf(__uint_as_float(raw[i] & 0xFFFF0000u), sc[2 * i + 1], sh[2 * i + 1]);
+            y0 = y0 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-CV_LOG2E * y0));
+            y1 = y1 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-CV_LOG2E * y1));
+            cv_bf16x2 pk;
+            pk[0] = (__bf16)y0;
+            pk[1] = (__bf16)y1;
+            raw[i] = __builtin_bit_cast(unsigned, pk);
         }
-        if (aoff[r] < 0) o = make_uint4(0, 0, 0, 0);  // zero padding applies to the activated operand
+    };
+    auto a_store = [&](int r, cv_u32x4 o, char* dst) __attribute__((always_inline)) {
+        if (aoff[r] < 0) o = cv_u32x4{0u, 0u, 0u, 0u};  // zero padding applies to the activated operand
         char* p = dst + a_wr + r * 64 * CV_PSTR;
-        if (r == CV_ROUNDS - 1 && prow + 64 * r >= CV_HPIX) p = smem + 2 * CV_ASZ + 2 * BSZ;  // dump slot (16 bytes)
-        if (hidden) {
-            // main loop: an LDS store hipcc knows of makes it wait vmcnt(0) first while an LDS-DMA is in flight (it cannot tell
-            // that the two never overlap) - mid-stage, behind requests issued a few hundred cycles earlier.  The store is
-            // retired by the lgkmcnt(0) in front of the barrier that ends the stage.
-            const cv_u32x4 ov = {o.x, o.y, o.z, o.w};
-            asm volatile("ds_write_b128 %0, %1" ::"v"(cv_lds_addr(p)), "v"(ov) : "memory");
-        } else {
-            *reinterpret_cast<uint4*>(p) = o;
-        }
+        if (r == CV_ROUNDS - 1 && prow + 64 * r >= CV_HPIX) p = smem + 2 * CV_ASZ;  // dump slot (16 bytes)
+        *reinterpret_cast<cv_u32x4*>(p) = o;
+    };
+    auto a_write = [&](int r, cv_u32x4 raw, char* dst) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) a_norm_pair(raw, i);
+        a_store(r, raw, dst);
     };
 
-    // ---- weight stages: (ct, chunk, tap) images of BSZ bytes, 512 threads x 16 bytes per round
-    const char* const wsrc = reinterpret_cast<const char*>(a.wp) + int64_t(ct) * nch * 9 * BSZ + tid * 16;
-    auto b_issue = [&](int stage, char* dst) __attribute__((always_inline)) {
-        const char* src = wsrc + int64_t(stage) * BSZ;
-#pragma unroll
-        for (int r = 0; r < BSZ / 8192; ++r) cv_glds16(src + r * 8192, dst + r * 8192 + wave * 1024);
-    };
+    // pixels (B operand): halo pixel (nbase + n + ky) * 34 + l31 + kx, 16-byte granule 2 ks + h
+    const unsigned xbase = unsigned(nbase * CV_HW + l31) * CV_PSTR + h * 16;
 
-    // ---- fragment addresses
-    // weights (A operand): row = w_m * MT*32 + m*32 + l31, 16-byte granule (2 ks + h) ^ ((row >> 1) & 7)
-    const unsigned wbase = unsigned(w_m * MT * 32 + l31) * 128 + (((unsigned(h) ^ ((unsigned(lane) >> 1) & 7u)) & 7u) << 4);
-    // pixels (B operand): halo pixel (2 w_n + n + ky) * 34 + l31 + kx, granule 2 ks + h
-    const unsigned xbase = unsigned((2 * w_n) * CV_HW + l31) * CV_PSTR + h * 16;
+    cv_f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 
-    cv_f32x16 acc[MT][2];
-#pragma unroll
-    for (int m = 0; m < MT; ++m)
-#pragma unroll
-        for (int n = 0; n < 2; ++n)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
-
-    // ---- prologue: chunk 0 halo + stage 0 weights
-    b_issue(0, bbuf);
+    // ---- prologue: chunk 0 halo
     gn_coeffs(0);
+    if (!(CV_ABL & 64))
 #pragma unroll
-    for (int r = 0; r < CV_ROUNDS; ++r) a_write(r, a_load(r, 0), abuf, false);
+        for (int r = 0; r < CV_ROUNDS; ++r) a_write(r, a_load(r, 0), abuf);
+    gn_coeffs((nch > 1 ? 1 : 0) * CV_KC);  // chunk 1 is staged during chunk 0
     __syncthreads();
 
-    unsigned bcur = 0, acur = 0;  // byte offsets of the current weight / halo buffer
-    cv_bf16x8 wf[2][MT], xf[2][2];
-    const int nstage = nch * 9;
+    unsigned acur = 0;  // byte offset of the current halo buffer
     for (int c = 0; c < nch; ++c) {
-        // the chunk staged during this one; past the end the last chunk is staged again into the buffer nobody reads any
-        // more (keeps the loop free of branches)
+        // the chunk staged during this one; past the end the last chunk is staged again into the buffer nobody reads any more
+        // (keeps the loop free of branches)
         const int c1 = (c + 1 < nch ? c + 1 : c) * CV_KC;
-        gn_coeffs(c1);
+        const int c2 = (c + 2 < nch ? c + 2 : nch - 1) * CV_KC;
         char* const anext = abuf + (acur ^ unsigned(CV_ASZ));
+        const char* const xl = abuf + acur + xbase;
+        const int kbase = c * 36;
         cv_u32x4 rawq[2];
+        cv_bf16x8 xf[2][4];
+        // fragments of group g+1 are requested before the MFMAs of group g (register double buffer); the order is pinned with
+        // sched_barrier: hipcc's own schedule issues each read right in front of its consumer and waits lgkmcnt(0) every 4 MFMAs
+        auto x_load = [&](int g, int s) __attribute__((always_inline)) {
+            const int J = g / NG, half = g % NG, t = J / 4, ks = J % 4, ky = t / 3, kx = t % 3;
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const int ky = t / 3, kx = t - ky * 3;
-            // piece t of the next chunk's halo: requested in stage t, normalised and written in stage t + 1 (the barrier that
-            // ends a stage drains vmcnt, so the request has the whole stage to come back from HBM)
-            if (t < CV_ROUNDS && !(CV_ABL & 16)) rawq[t & 1] = a_load_async(t, c1);
-            if (!(CV_ABL & 1)) {
-                const int s1 = c * 9 + t + 1;
-                b_issue(s1 < nstage ? s1 : nstage - 1, bbuf + (bcur ^ unsigned(BSZ)));
-            }
-            const char* const xl = abuf + acur + xbase + (ky * CV_HW + kx) * CV_PSTR;
-            // fragments of k-step ks+1 are requested before the MFMAs of k-step ks (register double buffer); the order is
-            // pinned with sched_barrier: hipcc's own schedule issues each read right in front of its consumer and waits
-            // lgkmcnt(0) every 4 MFMAs
-            auto frag_load = [&](int ks, int s) __attribute__((always_inline)) {
-                if (CV_ABL & 4) {
-                    if (c == 0 && t == 0 && ks == 0) {
+            for (int n = 0; n < 4; ++n)
+                xf[s][n] = *reinterpret_cast<const cv_bf16x8*>(xl + (half * 4 + n + ky) * ROWB + kx * CV_PSTR + ks * 32);
+        };
+        x_load(0, 0);
 #pragma unroll
-                        for (int m = 0; m < MT; ++m) wf[0][m] = wf[1][m] = *reinterpret_cast<const cv_bf16x8*>(bbuf + wbase + m * 4096);
-#pragma unroll
-                        for (int n = 0; n < 2; ++n) xf[0][n] = xf[1][n] = *reinterpret_cast<const cv_bf16x8*>(abuf + xbase + n * 64);
-                    }
-                    return;
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-                    wf[s][m] = *reinterpret_cast<const cv_bf16x8*>(bbuf + bcur + ((wbase ^ unsigned(ks << 5)) + m * 4096));
-#pragma unroll
-                for (int n = 0; n < 2; ++n) xf[s][n] = *reinterpret_cast<const cv_bf16x8*>(xl + n * CV_HW * CV_PSTR + ks * 32);
-            };
-            frag_load(0, 0);
-#pragma unroll
-            for (int ks = 0; ks < 4; ++ks) {
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks < 3) frag_load(ks + 1, (ks + 1) & 1);
-                __builtin_amdgcn_sched_barrier(0);
-                if (ks == 1 && t >= 1 && t <= CV_ROUNDS && !(CV_ABL & 16)) {  // normalisation VALU work beside this k-step's MFMAs
-                    // tie the piece to this point: without it the arithmetic (no side effects) is scheduled at the top of the
-                    // stage, directly behind its global load and a vmcnt(0)
-                    cv_u32x4& raw = rawq[(t - 1) & 1];
-                    asm volatile("" : "+v"(raw));
-                    a_write(t - 1, make_uint4(raw.x, raw.y, raw.z, raw.w), anext, true);
-                }
-#pragma unroll
-                for (int m = 0; m < MT; ++m)
-#pragma unroll
-                    for (int n = 0; n < 2; ++n) {
-                        if (CV_ABL & 2) asm volatile("" ::"v"(wf[ks & 1][m]), "v"(xf[ks & 1][n]));
-                        else acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[ks & 1][m], xf[ks & 1][n], acc[m][n], 0, 0, 0);
-                    }
-            }
+        for (int g = 0; g < NGRP; ++g) {
+            const int J = g / NG, half = g % NG, t = J / 4, ks = J % 4;
             __builtin_amdgcn_sched_barrier(0);
-            asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this stage's LDS-DMA, halo request and halo store are done
-            if (!(CV_ABL & 8)) __syncthreads();
-            bcur ^= unsigned(BSZ);
+            // piece t of the next chunk's halo: requested at the top of stage t, normalised and written during stage t + 1
+            if (ks == 0 && half == 0 && t < CV_ROUNDS && !(CV_ABL & 16)) rawq[t & 1] = a_load(t, c1);
+            if (g + 1 < NGRP && !(CV_ABL & 4)) x_load(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (t >= 1 && t <= CV_ROUNDS && !(CV_ABL & 16)) {
+                // the piece requested in the previous stage: one channel pair per quarter of the stage's groups, beside that
+                // group's MFMAs, the store with the last one - ~18 vector instructions per 4 MFMAs instead of ~75 in one place.
+                // The asm ties the arithmetic (no side effects) to this point: it would otherwise be scheduled directly behind
+                // the load, in front of a wait for it
+                constexpr int SG = 4 * NG;  // groups per stage
+                const int sg = ks * NG + half;
+                cv_u32x4& raw = rawq[(t - 1) & 1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+                    if (sg == (i * SG) / 4 + (SG > 4 ? 1 : 0)) {
+                        asm volatile("" : "+v"(raw));
+                        a_norm_pair(raw, i);
+                        if (i == 3) a_store(t - 1, raw, anext);
+                    }
+            }
+            if (t == 7 && ks == 0 && half == 0) gn_coeffs(c2);  // affine of the chunk staged during the NEXT chunk
+#pragma unroll
+            for (int n = 0; n < 4; ++n) {
+                if (CV_ABL & 2) asm volatile("" ::"v"(wr[J % D]), "v"(xf[g & 1][n]));
+                else acc[half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[J % D], xf[g & 1][n], acc[half * 4 + n], 0, 0, 0);
+            }
+            if (half == NG - 1 && !(CV_ABL & 1)) {  // the ring slot is free: request the fragment of k-step J + D
+                __builtin_amdgcn_sched_barrier(0);
+                const int jn = kbase + J + D;
+                wr[J % D] = *reinterpret_cast<const cv_bf16x8*>(wstream + int64_t(jn < nk ? jn : nk - 1) * 1024);
+            }
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // halo buffer hand-over: my stores are done, nobody reads the old buffer any more.  Raw barrier: __syncthreads() would
+        // also drain vmcnt, i.e. the weight ring
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        if (!(CV_ABL & 8)) __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
         acur ^= unsigned(CV_ASZ);
     }
 
@@ -300,38 +262,47 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
         __syncthreads();
     }
     const float* const bias = a.bias ? a.bias + int64_t(b) * a.bias_bstride + ct * CT : nullptr;
+    if ((CV_ABL & 32) && a.B > 0) {  // timing only: no epilogue (one store keeps the accumulators alive)
+        float t = 0.f;
 #pragma unroll
-    for (int m = 0; m < MT; ++m) {
-        const int chl = w_m * MT * 32 + m * 32 + 4 * h;  // + 8 q + j : channel inside the tile
+        for (int n = 0; n < NT; ++n) t += acc[n][0];
+        if (t == 123.456f) a.out[0] = (__bf16)t;
+    } else {
+        // the packed weights put channel 16 h + i of the wave's 32 on MFMA row (i & 3) + 8 (i >> 2) + 4 h, i.e. in accumulator
+        // register i of lane (pixel, h): a lane owns 16 CONSECUTIVE channels of one pixel = two 16-byte accesses
+        const int chl = wb * 32 + 16 * h;  // + i : channel inside the tile
         float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
         float4 bq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = bias ? *reinterpret_cast<const float4*>(bias + chl + 8 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int q = 0; q < 4; ++q) bq[q] = bias ? *reinterpret_cast<const float4*>(bias + chl + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int y = ty * CV_TH + 2 * w_n + n, px = tx * CV_TW + l31;
+        for (int n = 0; n < NT; ++n) {
+            const int y = ty * CV_TH + nbase + n, px = tx * CV_TW + l31;
             const int64_t o = ((int64_t(b) * H + y) * W + px) * a.cout + ct * CT + chl;
+            uint4 rr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+            if (a.residual) {
+                rr[0] = *reinterpret_cast<const uint4*>(a.residual + o);
+                rr[1] = *reinterpret_cast<const uint4*>(a.residual + o + 8);
+            }
+            const unsigned rw[8] = {rr[0].x, rr[0].y, rr[0].z, rr[0].w, rr[1].x, rr[1].y, rr[1].z, rr[1].w};
+            cv_bf16x8 pk[2];
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
-                float v[4] = {acc[m][n][4 * q] + bq[q].x, acc[m][n][4 * q + 1] + bq[q].y, acc[m][n][4 * q + 2] + bq[q].z,
-                              acc[m][n][4 * q + 3] + bq[q].w};
-                if (a.residual) {
-                    const uint2 rr = *reinterpret_cast<const uint2*>(a.residual + o + 8 * q);
-                    v[0] += __uint_as_float(rr.x << 16);
-                    v[1] += __uint_as_float(rr.x & 0xFFFF0000u);
-                    v[2] += __uint_as_float(rr.y << 16);
-                    v[3] += __uint_as_float(rr.y & 0xFFFF0000u);
-                }
-                cv_bf16x4 pk;
+                const float v[4] = {acc[n][4 * q] + bq[q].x + __uint_as_float(rw[2 * q] << 16),
+                                    acc[n][4 * q + 1] + bq[q].y + __uint_as_float(rw[2 * q] & 0xFFFF0000u),
+                                    acc[n][4 * q + 2] + bq[q].z + __uint_as_float(rw[2 * q + 1] << 16),
+                                    acc[n][4 * q + 3] + bq[q].w + __uint_as_float(rw[2 * q + 1] & 0xFFFF0000u)};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    pk[j] = (__bf16)v[j];
-                    const float vr = (float)pk[j];
+                    const __bf16 r = (__bf16)v[j];
+                    pk[q >> 1][(q & 1) * 4 + j] = r;
+                    const float vr = (float)r;
                     gs[q] += vr;
                     gq[q] = fmaf(vr, vr, gq[q]);
                 }
-                *reinterpret_cast<cv_bf16x4*>(a.out + o + 8 * q) = pk;
             }
+            *reinterpret_cast<cv_bf16x8*>(a.out + o) = pk[0];
+            *reinterpret_cast<cv_bf16x8*>(a.out + o + 8) = pk[1];
         }
         if (want_stats) {
 #pragma unroll
@@ -343,7 +314,7 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
                     ss += __shfl_xor(ss, off);
                 }
                 if (l31 == 0) {
-                    const int gl = (ct * CT + chl + 8 * q) / cg_out - g_first;
+                    const int gl = (ct * CT + chl + 4 * q) / cg_out - g_first;
                     atomicAdd(&sred[2 * gl], s);
                     atomicAdd(&sred[2 * gl + 1], ss);
                 }
@@ -357,29 +328,51 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
     }
 }
 
-// OHWI (cout, 9, cin) bf16 -> stage-major images [cout tile][chunk][tap][row][8 granules of 8 channels], granule g of row r
-// stored at position g ^ ((r >> 1) & 7): the 32-row fragment reads (ds_read_b128) of the kernel are then conflict free
+// OHWI (cout, 9, cin) bf16 -> fragment-ordered weight streams [cout tile][32-row block][chunk][tap][k-step][lane][8]: lane l of
+// the wave that owns a row block loads, per k-step, the 8 channels 16 ks + 8 (l >> 5) .. + 7 of row (l & 31) = its MFMA A
+// fragment, as ONE coalesced 16-byte-per-lane load; a wave's k-steps are contiguous (1 KiB each)
 __global__ void k_conv3x3_pack(const __bf16* __restrict__ w, int cout, int cin, int CT, __bf16* __restrict__ out) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // one 16-byte granule of the output
     const int64_t total = int64_t(cout) * 9 * cin / 8;
     if (i >= total) return;
     const int nch = cin / CV_KC;
-    const int gp = int(i & 7);
-    int64_t r_ = i >> 3;
-    const int row = int(r_ % CT);
-    r_ /= CT;
+    const int l = int(i & 63);
+    int64_t r_ = i >> 6;
+    const int ks = int(r_ & 3);
+    r_ >>= 2;
     const int t = int(r_ % 9);
     r_ /= 9;
     const int c = int(r_ % nch);
-    const int ct = int(r_ / nch);
-    const int g = gp ^ ((row >> 1) & 7);
-    const uint4 v = *reinterpret_cast<const uint4*>(w + (int64_t(ct * CT + row) * 9 + t) * cin + c * CV_KC + g * 8);
-    reinterpret_cast<uint4*>(out)[i] = v;
+    r_ /= nch;
+    const int wb = int(r_ % (CT / 32));
+    const int ct = int(r_ / (CT / 32));
+    const int rho = l & 31;  // MFMA row -> channel 16 h + i with rho = (i & 3) + 8 (i >> 2) + 4 h (see the kernel's epilogue)
+    const int row = ct * CT + wb * 32 + 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+    const int k = c * CV_KC + ks * 16 + (l >> 5) * 8;
+    reinterpret_cast<uint4*>(out)[i] = *reinterpret_cast<const uint4*>(w + (int64_t(row) * 9 + t) * cin + k);
+}
+
+// GroupNorm moments -> per-(image, channel) affine y = x * scale + shift, laid out [image][channel / 8][scale 8 | shift 8] so that
+// a staging thread of k_conv3x3 fetches the 16 coefficients of its 8 channels with four 16-byte loads
+// in_shift (C) or (B, C) with bstride = C, or null: the moments are those of x + in_shift (a bias the producer of x left to its
+// consumer), so y = (x + in_shift) * scale + shift
+__global__ void k_gn_affine(const double* __restrict__ stats, const float* __restrict__ gamma, const float* __restrict__ beta,
+                            const float* __restrict__ in_shift, int in_shift_bstride, int B, int C, int G, double inv_cnt, float eps,
+                            float* __restrict__ out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= B * C) return;
+    const int b = i / C, c = i - b * C, g = c / (C / G);
+    const double m = stats[(int64_t(b) * G + g) * 2] * inv_cnt;
+    const float var = float(stats[(int64_t(b) * G + g) * 2 + 1] * inv_cnt - m * m);
+    const float scale = gamma[c] * rsqrtf(fmaxf(var, 0.f) + eps);
+    float* o = out + (int64_t(b) * C + (c & ~7)) * 2 + (c & 7);
+    o[0] = scale;
+    o[8] = beta[c] + ((in_shift ? in_shift[int64_t(b) * in_shift_bstride + c] : 0.f) - float(m)) * scale;
 }
 
 template <int CT, int MODE, bool UPS>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
-    constexpr int LDS = 2 * CV_ASZ + 2 * CT * 128 + 16;
+    constexpr int LDS = 2 * CV_ASZ + 16;
     static bool configured = false;
     if (!configured) {
         XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CT, MODE, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -409,10 +402,12 @@ extern "C" int xm3d_conv3x3_pack_weight(const void* w_ohwi, int cout, int cin, i
     return XM3D_OK;
 }
 
+extern "C" int64_t xm3d_conv3x3_ws_bytes(int64_t B, int32_t cin) { return B > 0 && cin > 0 ? B * int64_t(cin) * 2 * int64_t(sizeof(float)) : 0; }
+
 extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin, const void* wpacked, int cout, int cout_tile,
-                                 const double* gn_stats, const float* gamma, const float* beta, float eps, int groups, int act,
-                                 const float* bias, int bias_bstride, const void* residual, void* out, double* stats_out,
-                                 int groups_out, int upsample, void* stream) {
+                                 const double* gn_stats, const float* gamma, const float* beta, const float* in_shift,
+                                 int in_shift_bstride, float eps, int groups, int act, const float* bias, int bias_bstride, const void* residual, void* out, double* stats_out,
+                                 int groups_out, int upsample, void* ws, void* stream) {
     XM3D_REQUIRE(x && wpacked && out, "conv3x3_nhwc: null pointer");
     XM3D_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && H % CV_TH == 0 && W % CV_TW == 0,
                  "conv3x3_nhwc: output %dx%d is not a multiple of the %dx%d pixel tile", H, W, CV_TH, CV_TW);
@@ -421,13 +416,16 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
                  cout, cout_tile);
     XM3D_REQUIRE(int64_t(H) * W * (cin > cout ? cin : cout) < (int64_t(1) << 31), "conv3x3_nhwc: image too large for 32-bit offsets");
     XM3D_REQUIRE(bias_bstride == 0 || bias_bstride == cout, "conv3x3_nhwc: bias_bstride must be 0 or cout");
+    XM3D_REQUIRE(in_shift_bstride == 0 || in_shift_bstride == cin, "conv3x3_nhwc: in_shift_bstride must be 0 or cin");
+    XM3D_REQUIRE(!in_shift || gn_stats, "conv3x3_nhwc: in_shift only applies to the GroupNorm input");
     XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(out) |
-                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta) |
-                   reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(gn_stats) | reinterpret_cast<uintptr_t>(stats_out)) & 15) == 0,
+                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(gn_stats) |
+                   reinterpret_cast<uintptr_t>(stats_out) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
                  "conv3x3_nhwc: tensors must be 16-byte aligned");
     const bool gn = gn_stats != nullptr;
     if (gn) {
-        XM3D_REQUIRE(gamma && beta && groups > 0 && cin % groups == 0 && (cin / groups) >= 4, "conv3x3_nhwc: GroupNorm needs gamma, beta and >= 4 channels per group");
+        XM3D_REQUIRE(gamma && beta && groups > 0 && cin % groups == 0, "conv3x3_nhwc: GroupNorm needs gamma, beta and groups dividing cin");
+        XM3D_REQUIRE(ws, "conv3x3_nhwc: GroupNorm needs a workspace of xm3d_conv3x3_ws_bytes(B, cin) bytes");
         XM3D_REQUIRE(act == 1, "conv3x3_nhwc: the fused GroupNorm is followed by SiLU (act 1)");
         XM3D_REQUIRE(!upsample, "conv3x3_nhwc: upsample and GroupNorm cannot be combined");
     } else {
@@ -437,12 +435,17 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
     if (stats_out)
         XM3D_REQUIRE(groups_out > 0 && cout % groups_out == 0 && (cout / groups_out) % 4 == 0 && cout_tile / (cout / groups_out) + 2 <= 128,
                      "conv3x3_nhwc: output statistics need a multiple of 4 channels per group (cout %d, groups %d)", cout, groups_out);
+    hipStream_t s = as_stream(stream);
     ConvArgs a;
     a.x = static_cast<const __bf16*>(x);
     a.wp = static_cast<const __bf16*>(wpacked);
-    a.gn_stats = gn_stats;
-    a.gamma = gamma;
-    a.beta = beta;
+    a.affine = nullptr;
+    if (gn) {
+        const int n = int(B) * cin;
+        hipLaunchKernelGGL(k_gn_affine, dim3((n + 255) / 256), dim3(256), 0, s, gn_stats, gamma, beta, in_shift, in_shift_bstride, int(B), cin, groups,
+                           1.0 / (double(H) * W * (cin / groups)), eps, static_cast<float*>(ws));
+        a.affine = static_cast<const float*>(ws);
+    }
     a.bias = bias;
     a.residual = static_cast<const __bf16*>(residual);
     a.out = static_cast<__bf16*>(out);
@@ -452,18 +455,12 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
     a.W = W;
     a.cin = cin;
     a.cout = cout;
-    a.groups_in = gn ? groups : 1;
-    a.cg_in = gn ? cin / groups : cin;
-    const int Hi = upsample ? H / 2 : H, Wi = upsample ? W / 2 : W;
-    a.inv_cnt_in = gn ? 1.0 / (double(Hi) * Wi * (cin / groups)) : 0.0;
-    a.eps = eps;
     a.bias_bstride = bias_bstride;
     a.groups_out = stats_out ? groups_out : 1;
     a.cg_out = stats_out ? cout / groups_out : cout;
     a.tiles_x = W / CV_TW;
     a.tiles_y = H / CV_TH;
     a.nct = cout / cout_tile;
-    hipStream_t s = as_stream(stream);
     if (cout_tile == 256) {
         if (gn) return launch_conv<256, 2, false>(a, s);
         return upsample ? launch_conv<256, 0, true>(a, s) : launch_conv<256, 0, false>(a, s);

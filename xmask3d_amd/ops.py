@@ -464,18 +464,25 @@ def bias_residual(a, b, bias, stats_groups=None):
 
 
 # ---------------------------------------------------------------- fused GroupNorm -> SiLU -> conv3x3 (conv.hip)
-def gn_stats_of(x, num_groups=32):
+def gn_stats_of(x, num_groups=32, shift=None):
     """(B*G*2,) f64 GroupNorm moments (sum, sum of squares per (sample, group)) of a channels-last tensor: taken from the tensor
-    if the kernel that produced it left them there (conv3x3 / bias_residual epilogues), else by one statistics pass."""
+    if the kernel that produced it left them there (conv3x3 / bias_residual epilogues), else by one statistics pass.
+    shift: (C,) or (B, C) tensor of x's dtype: moments of x + shift (always a pass)."""
     pre = getattr(x, "_xm3d_gn_stats", None)
-    if pre is not None and pre[1] == num_groups and pre[2] == x.data_ptr():
+    if pre is not None and shift is None and pre[1] == num_groups and pre[2] == x.data_ptr():
         return pre[0]
     if not is_nhwc(x) or x.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("gn_stats_of: channels-last f32/bf16 device tensor required")
     B, C, H, W = x.shape
     stats = torch.empty(B * num_groups * 2, dtype=torch.float64, device=x.device)
-    check(lib().xm3d_group_norm_nhwc_stats(_ptr(x), None, 0, 0 if x.dtype == torch.float32 else 1, B, C, H * W, num_groups, _ptr(stats), _stream()),
-          "xm3d_group_norm_nhwc_stats")
+    bstride = 0
+    if shift is not None:
+        shift = shift.to(x.dtype).contiguous()
+        if shift.numel() not in (C, B * C):
+            raise TypeError("gn_stats_of: shift must have C or B*C elements")
+        bstride = C if (shift.numel() == B * C and B > 1) else 0
+    check(lib().xm3d_group_norm_nhwc_stats(_ptr(x), _ptr(shift), bstride, 0 if x.dtype == torch.float32 else 1, B, C, H * W, num_groups, _ptr(stats),
+                                           _stream()), "xm3d_group_norm_nhwc_stats")
     return stats
 
 
@@ -501,12 +508,13 @@ def conv3x3_pack_weight(weight):
     return packed, tile
 
 
-def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_groups=None, upsample=False):
+def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_groups=None, upsample=False, in_shift=None):
     """out = conv3x3(SiLU(GroupNorm(x))) + bias (+ residual), channels-last bf16 (B, C, H, W) in and out.
     packed, tile: conv3x3_pack_weight(weight).  gn: None (plain convolution) or (stats f64 (B*G*2), gamma f32 (cin), beta f32 (cin),
     eps, G).  bias: None, (cout,) or (B, cout) f32.  residual: tensor like the output.  stats_groups: G of the GroupNorm that reads
     the result next - its moments are accumulated in the epilogue and attached to the returned tensor (gn_stats_of picks them up).
-    upsample: x is nearest-upsampled 2x first (plain convolution only)."""
+    upsample: x is nearest-upsampled 2x first (plain convolution only).
+    in_shift: (cin,) or (B, cin) f32 added to x in front of the GroupNorm (gn's moments must be those of x + in_shift)."""
     if not conv3x3_supported(x, cout, upsample):
         raise TypeError(f"conv3x3: unsupported input {tuple(x.shape)} {x.dtype} (channels-last bf16, H % 8, W % 32, cin % 64, cout % 128)")
     B, cin, H, W = x.shape
@@ -528,12 +536,19 @@ def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_grou
                 or gamma.numel() != cin or beta.numel() != cin:
             raise TypeError("conv3x3: gn = (f64 moments (B*G*2), f32 gamma (cin), f32 beta (cin), eps, G)")
         act = 1
-    stats_out = None
+    sstride = 0
+    if in_shift is not None:
+        if gn is None or in_shift.dtype != torch.float32 or not in_shift.is_contiguous() or in_shift.numel() not in (cin, B * cin):
+            raise TypeError("conv3x3: in_shift needs gn and must be a contiguous f32 (cin,) or (B, cin) tensor")
+        sstride = cin if (in_shift.numel() == B * cin and B > 1) else 0
+    stats_out = ws = None
     if stats_groups:
         stats_out = torch.zeros(B * stats_groups * 2, dtype=torch.float64, device=x.device)
-    check(lib().xm3d_conv3x3_nhwc(_ptr(x), B, H, W, cin, _ptr(packed), cout, tile, _ptr(stats_in), _ptr(gamma), _ptr(beta), float(eps), int(G), act,
-                                  _ptr(bias), bstride, _ptr(residual), _ptr(out), _ptr(stats_out), int(stats_groups or 0), int(bool(upsample)),
-                                  _stream()), "xm3d_conv3x3_nhwc")
+    if gn is not None:
+        ws = torch.empty(B * cin * 2, dtype=torch.float32, device=x.device)
+    check(lib().xm3d_conv3x3_nhwc(_ptr(x), B, H, W, cin, _ptr(packed), cout, tile, _ptr(stats_in), _ptr(gamma), _ptr(beta), _ptr(in_shift), sstride,
+                                  float(eps), int(G), act, _ptr(bias), bstride, _ptr(residual), _ptr(out), _ptr(stats_out), int(stats_groups or 0), int(bool(upsample)),
+                                  _ptr(ws), _stream()), "xm3d_conv3x3_nhwc")
     if stats_out is not None:
         out._xm3d_gn_stats = (stats_out, int(stats_groups), out.data_ptr())
     return out

@@ -20,6 +20,7 @@ decoder; `taps` arguments name the blocks whose INPUT is returned as a feature.
 from __future__ import annotations
 
 import math
+import os
 
 import torch
 import torch.nn as nn
@@ -48,6 +49,52 @@ def fused_nhwc(x):
 
 def conv_nobias(conv: nn.Conv2d, x):
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
+
+
+# ---- fused GroupNorm -> SiLU -> conv3x3 (csrc/conv.hip, xm3d_conv3x3_nhwc): the ResnetBlock halves of both frozen nets
+def fused_conv_ok(x, conv, upsample=False):
+    """bf16 channels-last inference on a shape the HIP convolution takes (XM3D_CONV=library switches it off for A/B runs)"""
+    return (fused_nhwc(x) and x.dtype == torch.bfloat16 and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1)
+            and conv.dilation == (1, 1) and conv.groups == 1 and x.shape[1] == conv.in_channels and os.environ.get("XM3D_CONV", "hip") != "library"
+            and ops.conv3x3_supported(x, conv.out_channels, upsample))
+
+
+def _packed(conv):
+    """(packed weight, cout tile, f32 bias) of a frozen Conv2d, built once per weight storage"""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.dtype)
+    c = conv.__dict__.get("_xm3d_pack")
+    if c is None or c[0] != key:
+        packed, tile = ops.conv3x3_pack_weight(w)
+        c = conv.__dict__["_xm3d_pack"] = (key, packed, tile, None if conv.bias is None else conv.bias.detach().float().contiguous())
+    return c[1], c[2], c[3]
+
+
+def _gn_f32(norm):
+    w = norm.weight
+    key = (w.data_ptr(), w._version, w.dtype)
+    c = norm.__dict__.get("_xm3d_f32")
+    if c is None or c[0] != key:
+        c = norm.__dict__["_xm3d_f32"] = (key, norm.weight.detach().float().contiguous(), norm.bias.detach().float().contiguous())
+    return c[1], c[2]
+
+
+def gn_silu_conv3x3(norm, conv, x, pend=None, bias=None, residual=None):
+    """conv(SiLU(norm(x + pend))) + bias (+ residual) in one launch; bias None = the convolution's own.  The moments of x come from
+    the kernel that produced it when it left them on the tensor, and the moments of the result are left on it for the next norm."""
+    packed, tile, own_bias = _packed(conv)
+    gamma, beta = _gn_f32(norm)
+    stats = ops.gn_stats_of(x, norm.num_groups, shift=pend)
+    return ops.conv3x3(x, packed, conv.out_channels, tile, bias=own_bias if bias is None else bias, gn=(stats, gamma, beta, norm.eps, norm.num_groups),
+                       residual=residual, stats_groups=32 if (conv.out_channels // 32) % 4 == 0 else None,
+                       in_shift=None if pend is None else pend.detach().float().contiguous())
+
+
+def plain_conv3x3(conv, x, upsample=False):
+    """conv(x) + bias (x nearest-upsampled 2x first if asked), moments of the result left on it"""
+    packed, tile, own_bias = _packed(conv)
+    return ops.conv3x3(x, packed, conv.out_channels, tile, bias=own_bias, upsample=upsample,
+                       stats_groups=32 if (conv.out_channels // 32) % 4 == 0 else None)
 
 
 def bias_residual(skip, h, bias):
@@ -98,6 +145,19 @@ class VaeResBlock(nn.Module):
     def forward(self, x, temb=None, pend=None):
         """pend: (C,) bias of the convolution that produced x and has NOT been added yet (conv_in / Downsample / Upsample of
         the fused channels-last path): it rides in norm1's shift and in the residual add instead of a pass of its own."""
+        if fused_conv_ok(x, self.conv1) and self.conv2.out_channels % 128 == 0:
+            # both halves on the HIP convolution: normalisation on the staged input tile, bias / skip in the epilogue, and the
+            # moments for the next GroupNorm from the epilogue as well
+            h = gn_silu_conv3x3(self.norm1, self.conv1, x, pend=pend)
+            bias, skip = None, x
+            if self.in_channels != self.out_channels:
+                skip = conv_nobias(self.nin_shortcut, x)
+                bias = self.conv2.bias.float() + self.nin_shortcut.bias.float()
+                if pend is not None:  # the 1x1 shortcut of a constant: W @ pend
+                    bias = bias + (self.nin_shortcut.weight.flatten(1) @ pend.to(self.nin_shortcut.weight.dtype)).float()
+            elif pend is not None:
+                bias = self.conv2.bias.float() + pend.float()
+            return gn_silu_conv3x3(self.norm2, self.conv2, h, bias=bias, residual=skip)
         if fused_nhwc(x):  # conv1's bias rides in norm2's shift, conv2's (and the shortcut's) in the residual add
             h = conv_nobias(self.conv1, gn_act(self.norm1, x, ACT_SILU, pend))
             h = conv_nobias(self.conv2, gn_act(self.norm2, h, ACT_SILU, self.conv1.bias))
@@ -172,6 +232,9 @@ class VaeUpsample(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x, defer_bias=False):
+        if fused_conv_ok(x, self.conv, upsample=True):  # the nearest 2x upsampling is a shift of the staging address
+            out = plain_conv3x3(self.conv, x, upsample=True)
+            return (out, None) if defer_bias else out
         up = F.interpolate(x, scale_factor=2.0, mode="nearest")
         if defer_bias and fused_nhwc(up):
             return conv_nobias(self.conv, up), self.conv.bias
@@ -305,6 +368,15 @@ class UNetResBlock(nn.Module):
         self.skip_connection = nn.Identity() if cin == cout else nn.Conv2d(cin, cout, 1)
 
     def forward(self, x, emb):
+        if fused_conv_ok(x, self.in_layers[2]) and self.out_channels % 128 == 0:
+            # HIP convolutions: the timestep-embedding term is a per-sample bias of the first one
+            bias1 = (self.emb_layers(emb).float() + self.in_layers[2].bias.float()).contiguous()
+            h = gn_silu_conv3x3(self.in_layers[0], self.in_layers[2], x, bias=bias1)
+            bias, skip = None, x
+            if not isinstance(self.skip_connection, nn.Identity):
+                skip = conv_nobias(self.skip_connection, x)
+                bias = self.out_layers[3].bias.float() + self.skip_connection.bias.float()
+            return gn_silu_conv3x3(self.out_layers[0], self.out_layers[3], h, bias=bias, residual=skip)
         if fused_nhwc(x):  # first conv's bias + the embedding term ride in the second GroupNorm's shift
             h = conv_nobias(self.in_layers[2], gn_act(self.in_layers[0], x, ACT_SILU))
             shift = self.emb_layers(emb).to(h.dtype) + self.in_layers[2].bias
@@ -423,6 +495,9 @@ class UNetUpsample(nn.Module):
         self.conv = nn.Conv2d(c, c, 3, padding=1)
 
     def forward(self, x, defer_bias=False):
+        if fused_conv_ok(x, self.conv, upsample=True):
+            out = plain_conv3x3(self.conv, x, upsample=True)
+            return (out, None) if defer_bias else out
         up = F.interpolate(x, scale_factor=2.0, mode="nearest")
         if defer_bias and fused_nhwc(up):
             return conv_nobias(self.conv, up), self.conv.bias
