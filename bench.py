@@ -31,7 +31,7 @@ FP32_MFMA_PEAK_TF = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_16x16x4_f32 peak
 BF16_MFMA_PEAK_TF = 2500.0  # dense bf16
 HBM_PEAK_GBPS = 8000.0      # HBM3E spec (6.3 TB/s measured copy)
 L2_PEAK_GBPS = 34500.0      # aggregate L2 rate (MI355X_MICROARCH.md, L2 section)
-SPCONV_PMC_TRAFFIC_BYTES = 153.0e6  # profiles/r02_roofline_spconv_pmc.txt: 2 x FETCH_SIZE (gfx950 read correction) 70.8 MB + WRITE_SIZE 82.2 MB
+PMC_FILE = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "roofline_pmc.json")
 DENSE_TFLOP_PER_VIEW_MIN = 2.83  # SURVEY.md §8d, dead compute pruned
 DENSE_TFLOP_PER_VIEW_REF = 4.79  # as the reference computes
 
@@ -61,6 +61,47 @@ def event_ms(fn, reps, stream=None):
     end.record()
     torch.cuda.synchronize()
     return start.elapsed_time(end) / reps
+
+
+def pmc_traffic(kernel_key):
+    """HBM-side bytes per launch of a kernel from the committed rocprofv3 PMC summary (profiles/roofline_pmc.json, written by
+    tools/pmc_summary.py from separate FETCH_SIZE / WRITE_SIZE passes of `bench.py --roofline-only`, FETCH_SIZE doubled as
+    MI355X_MICROARCH.md prescribes for gfx950); None if the file has no entry for it"""
+    try:
+        with open(PMC_FILE) as f:
+            ent = json.load(f).get(kernel_key)
+        return None if ent is None else float(ent["traffic_bytes"])
+    except (OSError, ValueError, KeyError):
+        return None
+
+
+def conv_roofline(dev):
+    """Roofline of the time-dominant hand-written kernel, k_conv3x3<256,2,false> (csrc/conv.hip), on the shape with the largest
+    share of the forward: the 512 -> 512 channel ResnetBlock convolution of the SD VAE at 128 x 128, 20 views, with everything
+    the bench forward fuses into it (GroupNorm affine + SiLU on the staged input, bias, residual, output moments).
+    Algorithmic FLOP = 2 * B*H*W * 9*Cin * Cout per launch; bytes = input + residual + output (bf16) + weights."""
+    from xmask3d_amd import ops
+
+    B, C, H, W, G = 20, 512, 128, 128, 32
+    g = torch.Generator(device="cpu").manual_seed(7)
+    x = torch.randn(B, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    res = torch.randn(B, C, H, W, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(dev)
+    gamma, beta, bias = torch.ones(C, device=dev), torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    packed, tile = ops.conv3x3_pack_weight(w)
+    stats = ops.gn_stats_of(x, G)
+    ms = event_ms(lambda: ops.conv3x3(x, packed, C, tile, bias=bias, gn=(stats, gamma, beta, 1e-6, G), residual=res, stats_groups=G), 10)
+    ms_plain = event_ms(lambda: ops.conv3x3(x, packed, C, tile, bias=bias), 10)
+    wl = w.to(torch.bfloat16).contiguous(memory_format=torch.channels_last)
+    ms_lib = event_ms(lambda: torch.nn.functional.conv2d(x, wl, None, padding=1), 10)
+    flop = 2.0 * B * H * W * 9 * C * C
+    nbytes = B * H * W * (C + 2 * C) * 2 + 9 * C * C * 2
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"kernel": "xm3d::k_conv3x3<256,2,false>", "bound": "mfma", "achieved": tf, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": tf / BF16_MFMA_PEAK_TF, "traffic": pmc_traffic("k_conv3x3<256,2,false>"), "algorithmic_bytes": nbytes,
+            "avg_launch_us": ms * 1e3, "shape": f"{B} x {H}x{W} x {C}->{C}, GroupNorm(32)+SiLU in, bias+residual+moments out",
+            "plain_conv_us": ms_plain * 1e3, "plain_conv_frac": flop / (ms_plain * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF,
+            "library_conv_alone_us": ms_lib * 1e3, "library_conv_alone_frac": flop / (ms_lib * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF}
 
 
 def spconv_roofline(dev):
@@ -96,7 +137,7 @@ def spconv_roofline(dev):
     return {"kernel": "xm3d::k_spconv_split<6,1,96,4,3,2,true>", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF,
             "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
             # HBM-side bytes per launch from rocprofv3 PMC passes on `bench.py --roofline-only` (profiles/r02_roofline_spconv_pmc.txt)
-            "traffic": SPCONV_PMC_TRAFFIC_BYTES, "algorithmic_bytes_gather_scatter": gs_bytes,
+            "traffic": pmc_traffic("k_spconv_split<6,1,96,4,3,2,true>"), "algorithmic_bytes_gather_scatter": gs_bytes,
             "algorithmic_bytes_compulsory": (2 * n * cin + 27 * cin * cout) * 4 + 8 * pairs,
             "avg_launch_us": ms * 1e3, "pairs": pairs, "voxels": n, "cin": cin, "cout": cout,
             "gather_scatter_GBps": gs_bytes / (ms * 1e-3) / 1e9,
@@ -266,7 +307,7 @@ def main():
             dist.init_process_group(backend=backend)
 
     if args.roofline_only:
-        print(json.dumps({"roofline": spconv_roofline(dev)}))
+        print(json.dumps({"roofline": conv_roofline(dev), "roofline_spconv": spconv_roofline(dev)}))
         return
 
     import __graft_entry__
@@ -449,16 +490,18 @@ def main():
     dense_tflop = DENSE_TFLOP_PER_VIEW_REF if args.faithful_dead_compute else DENSE_TFLOP_PER_VIEW_MIN
     peak = BF16_MFMA_PEAK_TF if args.dtype == "bf16" else FP32_MFMA_PEAK_TF
     log(f"dense branch {dense_ms:.1f} ms/view, sparse branch {sparse_ms:.1f} ms/view; kernel roofline")
-    roof_kernel = spconv_roofline(dev)
-    # `roofline`: kernel-level, the dominant hand-written kernel (k_spconv_split), HIP events live + PMC traffic from profiles/
-    roofline = dict(roof_kernel)
-    roofline["scope"] = ("dominant hand-written HIP kernel; algorithmic FLOP = 2*pairs*cin*cout per launch (SURVEY 8d), one launch = "
-                         "one sparse-conv layer of MinkUNet34C block8 on the full S1 cloud; the scene-level time is dominated by the "
-                         "library-kernel dense stage reported under roofline_dense_stage")
+    # `roofline`: kernel-level, the time-dominant hand-written kernel (k_conv3x3: 28 % of the device time of the timed window),
+    # HIP events live + PMC traffic from profiles/; `roofline_spconv`: the dominant kernel of the sparse 3D branch
+    roofline = conv_roofline(dev)
+    roofline["scope"] = ("time-dominant hand-written HIP kernel (fused GroupNorm-SiLU-conv3x3 of the SD VAE / UNet ResnetBlocks); algorithmic "
+                         "FLOP = 2*B*H*W*9*Cin*Cout per launch, one launch = one ResnetBlock convolution of the VAE at 128x128 on 20 views")
+    roofline_spconv = spconv_roofline(dev)
+    roofline_spconv["scope"] = ("dominant kernel of the sparse 3D branch; algorithmic FLOP = 2*pairs*cin*cout per launch (SURVEY 8d), one launch = "
+                                "one sparse-conv layer of MinkUNet34C block8 on the full S1 cloud")
     roofline_stage = {"bound": "mfma", "achieved": dense_tflop / (dense_ms * 1e-3), "peak": peak, "unit": "TFLOP/s",
                       "frac": dense_tflop / (dense_ms * 1e-3) / peak, "traffic": None, "views_per_forward": vb,
-                      "scope": "dense 2D branch per view (SD VAE+UNet, projections, pixel+transformer decoder, mask-CLIP): MIOpen / hipBLASLt "
-                               "kernels + HIP flash attention (VAE d=512 head: GEMM + HIP row softmax + GEMM) + HIP GroupNorm / LayerNorm / pointwise kernels, " + ("HIP graph replay" if not args.no_graph else "eager launches"),
+                      "scope": "dense 2D branch per view (SD VAE+UNet, projections, pixel+transformer decoder, mask-CLIP): HIP fused GroupNorm-SiLU-conv3x3 "
+                               "for the ResnetBlocks, MIOpen / hipBLASLt for the other convolutions / GEMMs, HIP flash attention (VAE d=512 head: GEMM + HIP row softmax + GEMM) + HIP GroupNorm / LayerNorm / pointwise kernels, " + ("HIP graph replay" if not args.no_graph else "eager launches"),
                       "ms_per_view": dense_ms, "algorithmic_tflop_per_view": dense_tflop, "sparse3d_ms_per_view": sparse_ms}
 
     cpu_baseline = None
@@ -485,7 +528,7 @@ def main():
                    "dead_compute": "as reference" if args.faithful_dead_compute else "pruned (SURVEY F7)",
                    "layout": "NCHW" if args.nchw else "channels-last (NHWC) frozen nets",
                    "schedule": "eager launches" if args.no_graph else "3 HIP graphs per forward (2 slots), next forward's front software-pipelined on side streams"},
-        "roofline": roofline, "roofline_dense_stage": roofline_stage, "roofline_kernels": kernel_rooflines(dev),
+        "roofline": roofline, "roofline_spconv": roofline_spconv, "roofline_dense_stage": roofline_stage, "roofline_kernels": kernel_rooflines(dev),
         "cpu_baseline": cpu_baseline, "latency_ms_single_scene": latency_ms, "fp32": fp32, "train": None,
     }
     finish(None)
