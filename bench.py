@@ -445,16 +445,24 @@ def main():
         import threading
 
         def on_timeout():
-            faulthandler.dump_traceback(file=sys.stderr)
+            # a leg that does not finish is a FAILURE of this run: the stacks of every python thread name the blocking call, the
+            # inference line measured above is still printed (with train_error), and the exit code is non-zero
+            print(f"[bench] rank {rank}: training leg exceeded {args.train_deadline} s; python stacks follow", file=sys.stderr, flush=True)
+            faulthandler.dump_traceback(file=sys.stderr, all_threads=True)
             if rank == 0:
                 out["train"] = None
-                out["train_error"] = f"training leg did not finish within {args.train_deadline} s (python stacks on stderr); inference line unaffected"
+                out["train_error"] = (f"training leg did not finish within {args.train_deadline} s (python stacks of all threads on stderr); "
+                                      "inference line unaffected; exit code 3")
                 print(json.dumps(out), flush=True)
             sys.stderr.flush()
-            os._exit(0)
+            os._exit(3)
 
         timer = None
         if args.train_steps > 0:
+            if world > 1:
+                # rank 0 reaches this point after its roofline / baseline measurements, the other ranks right after the timed
+                # region: meet here, so that every rank's deadline starts when the leg does
+                dist.barrier()
             timer = threading.Timer(args.train_deadline, on_timeout)
             timer.daemon = True
             timer.start()

@@ -59,6 +59,69 @@ class LatentDiffusion(nn.Module):
         return self.unet_model
 
 
+class _GraphedTaps:
+    """fn(latent, ctx, emb) -> tuple of tensors, differentiable w.r.t. ctx and emb, replayed as ONE forward and ONE backward HIP
+    graph.  Same idea as torch.cuda.make_graphed_callables, but every tensor autograd sees during warm-up and capture - the
+    static input leaves included - is CREATED ON THE PRIVATE CAPTURE STREAM: with make_graphed_callables the sample leaves were
+    made on the caller's (default) stream, so their AccumulateGrad nodes belonged to that stream while the capture ran on
+    another one ("The AccumulateGrad node's stream does not match ... may break CUDA graph capture" in every log of round 2):
+    the engine then orders the capture stream against the legacy stream inside the capture.  One backward replay of such a
+    pair ended in a segmentation fault in hipGraphLaunch (round-2 GPU test log).  Here nothing in either capture refers to
+    another stream, the private memory pool and both graphs live as long as this object, and the gradients handed back are
+    copies (the static ones are overwritten by the next replay)."""
+
+    def __init__(self, fn, latent, ctx, emb, warmup=3):
+        self.stream = torch.cuda.Stream()
+        self.stream.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(self.stream):
+            self.lat = latent.detach().clone()
+            self.ctx = ctx.detach().clone().requires_grad_(True)
+            self.emb = emb.detach().clone().requires_grad_(True)
+            for _ in range(warmup):  # library algorithm selection and allocator warm-up, outside any capture
+                outs = fn(self.lat, self.ctx, self.emb)
+                torch.autograd.grad(outs, (self.ctx, self.emb), [torch.ones_like(o) for o in outs])
+            del outs
+        torch.cuda.current_stream().wait_stream(self.stream)
+        torch.cuda.synchronize()
+        self.pool = torch.cuda.graph_pool_handle()
+        self.fwd, self.bwd = torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.fwd, pool=self.pool, stream=self.stream):
+            self.outs = tuple(fn(self.lat, self.ctx, self.emb))
+        with torch.cuda.stream(self.stream):
+            self.gouts = [torch.zeros_like(o) for o in self.outs]
+        self.stream.synchronize()
+        with torch.cuda.graph(self.bwd, pool=self.pool, stream=self.stream):
+            self.gins = torch.autograd.grad(self.outs, (self.ctx, self.emb), self.gouts, only_inputs=True)
+        torch.cuda.synchronize()
+
+    def __call__(self, latent, ctx, emb):
+        return _GraphedTapsFn.apply(self, latent, ctx, emb)
+
+
+class _GraphedTapsFn(torch.autograd.Function):
+    @staticmethod
+    def forward(c, g, latent, ctx, emb):
+        with torch.no_grad():
+            g.lat.copy_(latent)
+            g.ctx.copy_(ctx)
+            g.emb.copy_(emb)
+        g.fwd.replay()
+        c.g = g
+        return tuple(o.detach().clone() for o in g.outs)  # the static outputs are overwritten by the next replay
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(c, *grads):
+        g = c.g
+        for dst, src in zip(g.gouts, grads):
+            if src is None:
+                dst.zero_()
+            else:
+                dst.copy_(src)
+        g.bwd.replay()
+        return None, None, g.gins[0].detach().clone(), g.gins[1].detach().clone()
+
+
 class LdmExtractor(nn.Module):
     def __init__(self, encoder_block_indices=(5, 7), unet_block_indices=(2, 5, 8, 11), decoder_block_indices=(2, 5),
                  steps=(0,), prune_dead_compute=True):
@@ -128,9 +191,9 @@ class LdmExtractor(nn.Module):
                              stop_after_taps=self.prune_dead_compute)[1]
 
     def enable_train_graph(self, on=True):
-        """Training: replay the frozen UNet's forward AND backward as HIP graphs (torch.cuda.make_graphed_callables), one
-        pair per input shape.  The UNet is the only frozen net a gradient passes through (to the 3D conditioning); eagerly
-        its ~1500 forward and ~3000 backward launches are host-bound at one view per GPU."""
+        """Training: replay the frozen UNet's forward AND backward as a pair of HIP graphs (_GraphedTaps), one pair per input
+        shape.  The UNet is the only frozen net a gradient passes through (to the 3D conditioning); eagerly its ~1500 forward
+        and ~3000 backward launches are host-bound at one view per GPU."""
         self._train_graphs = {} if on else None
         return self
 
@@ -144,9 +207,7 @@ class LdmExtractor(nn.Module):
                 def forward(self, lat, ctx, emb):
                     return tuple(ext.unet_taps(lat, ctx, emb))
 
-            sample = (latent.detach().clone(), cond_inputs.detach().clone().requires_grad_(True),
-                      cond_emb.detach().clone().requires_grad_(True))
-            fn = self._train_graphs[key] = torch.cuda.make_graphed_callables(_UNetTaps().eval(), sample)
+            fn = self._train_graphs[key] = _GraphedTaps(_UNetTaps().eval(), latent, cond_inputs, cond_emb)
         return list(fn(latent, cond_inputs, cond_emb))
 
     def from_latent(self, latent, enc_feats, cond_inputs, cond_emb, fork_stream=None):
