@@ -129,6 +129,24 @@ class CLIP(nn.Module):
         nn.init.normal_(self.text_projection, std=text_width ** -0.5)
 
 
+class TextTower(nn.Module):
+    """the text side of CLIP ViT-L/14 alone (same parameter names): what ldm's FrozenCLIPEmbedder runs for Stable Diffusion's
+    conditioning - token + positional embedding, 12 causal blocks, final LayerNorm; forward(tokens) -> hidden states (n, 77, 768)
+    (HuggingFace ``last_hidden_state``).  Used once, on the CPU, to compute ``uncond_inputs`` (ldm.py:105)."""
+
+    def __init__(self, width=768, layers=12, heads=12):
+        super().__init__()
+        self.transformer = Transformer(width, layers, heads)
+        self.token_embedding = nn.Embedding(VOCAB, width)
+        self.positional_embedding = nn.Parameter(torch.zeros(CONTEXT, width))
+        self.ln_final = nn.LayerNorm(width)
+        self.register_buffer("attn_mask", torch.ones(CONTEXT, CONTEXT, dtype=torch.bool).tril(), persistent=False)
+
+    def forward(self, tokens):
+        x = self.token_embedding(tokens) + self.positional_embedding
+        return self.ln_final(self.transformer(x, self.attn_mask))
+
+
 def tokenize_standin(texts, context_length=CONTEXT):
     """Deterministic stand-in for open_clip.tokenize: one id per whitespace token (crc32 into the vocab)."""
     if isinstance(texts, str):
@@ -156,6 +174,11 @@ class ClipAdapter(nn.Module):
         self.clip.eval()
         for p in self.clip.parameters():
             p.requires_grad = False
+
+    def set_tokenizer(self, bpe):
+        """a bpe.ClipBPE built from local vocabulary files replaces the stand-in (open_clip.tokenize semantics: pad with 0)"""
+        self.tokenize = lambda texts, context_length=CONTEXT: bpe(texts, context_length=context_length, pad_id=0)
+        self.bpe = bpe
 
     def train(self, mode=True):
         super().train(mode)
@@ -252,6 +275,13 @@ class CategoryEmbed(nn.Module):
         self.text_proj = nn.Identity() if projection_dim < 0 else nn.Linear(self.clip.dim_latent, projection_dim)
         self.register_buffer("text_embed", self.clip.build_text_embed(labels), False)
         self.null_embed = nn.Parameter(self.clip.build_text_embed(""))
+        self._test_cache = {}
+
+    @torch.no_grad()
+    def refresh(self):
+        """recompute what the constructor derived from the CLIP text tower (after its weights / tokenizer were replaced)"""
+        self.text_embed.copy_(self.clip.build_text_embed(self.labels).to(self.text_embed))
+        self.null_embed.copy_(self.clip.build_text_embed("").to(self.null_embed))
         self._test_cache = {}
 
     def forward(self, outputs=None, targets=None):

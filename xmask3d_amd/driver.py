@@ -131,9 +131,24 @@ def train(cfg, epochs=1, iters_per_epoch=4, views_per_gpu=2, save_path=None, res
     return model
 
 
+def scannet_scene_list(cfg, split="val"):
+    """Scene names of the reference's on-disk validation set (<data_root>/<split>/*_vh_clean_2.pth, sorted like
+    ScannetLoaderFull: data_loader_infer.py:60-75) when both data directories exist, else None (synthetic scenes)."""
+    import glob
+
+    d3, d2 = str(getattr(cfg, "data_root", "") or ""), str(getattr(cfg, "data_root_2d", "") or "")
+    if not (os.path.isdir(os.path.join(d3, split)) and os.path.isdir(d2)):
+        return None
+    names = sorted(os.path.basename(p)[:-len("_vh_clean_2.pth")] for p in glob.glob(os.path.join(d3, split, "*_vh_clean_2.pth")))
+    return [n for n in names if os.path.isdir(os.path.join(d2, n))] or None
+
+
 @torch.no_grad()
 def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, log=print):
-    """-> dict of open-vocabulary scores for the fused / 2D / 3D predictions (infer.py:696-911 bookkeeping)."""
+    """-> dict of open-vocabulary scores for the fused / 2D / 3D predictions (infer.py:696-911 bookkeeping).
+    When cfg.data_root / cfg.data_root_2d hold the reference's ScanNet layout (scannet.py), the validation scenes found there
+    are read (point cloud, frames, depth, poses, captions, the reference's frame filter) and scored against their labels;
+    `scenes` then caps how many (None / 0 = all).  Otherwise `scenes` synthetic rooms with synthetic labels."""
     rank, world, dev = setup_distributed(cfg)
     own = model is None
     if own:
@@ -156,14 +171,31 @@ def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, lo
     K = cfg.test_classes
     names = ("fused", "2d", "3d")
     acc = torch.zeros(3, 3, K, device=dev)
+    real = scannet_scene_list(cfg)
+    if real is not None:
+        if scenes:
+            real = real[:scenes]
+        scenes = len(real)
+        if rank == 0:
+            log(f"infer: {scenes} ScanNet scene(s) from {cfg.data_root} / {cfg.data_root_2d}")
     mine = list(range(rank, scenes, world))  # DistributedSampler(shuffle=False) partition
     G = max(1, int(getattr(cfg, "scenes_per_forward", 4)))  # scenes whose views share one forward (pipeline.infer_scenes)
     chunks = [mine[i:i + G] for i in range(0, len(mine), G)]
 
     vox = pipeline.default_voxelizer(cfg.voxel_size, dev)
 
+    def load_real(s):
+        from . import scannet
+
+        sc, frames = scannet.load_scene(cfg.data_root, cfg.data_root_2d, real[s], split="val", caption_path=getattr(cfg, "caption_path", None),
+                                        ignore_label=cfg.category_split["ignore_category"][-1], device=dev,
+                                        val_keep=int(getattr(cfg, "val_keep", 10000000)), ignore_categories=cfg.category_split["ignore_category"])
+        if not frames:
+            raise RuntimeError(f"scene {real[s]}: no frame passes the visibility filter (data_loader_infer.py:199-209)")
+        return sc
+
     def upload(chunk):
-        scs = [synthetic.scene_s1(seed=cfg.manual_seed + s) for s in chunk]
+        scs = [load_real(s) if real is not None else synthetic.scene_s1(seed=cfg.manual_seed + s) for s in chunk]
         mats = []
         for s, sc in zip(chunk, scs):  # the augmentation draws of a scene depend on its index alone (not on grouping / prefetch order)
             np.random.seed(cfg.manual_seed + s)
@@ -174,10 +206,16 @@ def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, lo
     for ci, chunk in enumerate(chunks):
         scs, sds, mats = nxt
         nxt = upload(chunks[ci + 1]) if ci + 1 < len(chunks) else None  # resident before this chunk's forward is issued
-        results = pipeline.infer_scenes(model, sds, cfg, vox, mats, next_scenes=None if nxt is None else nxt[1],
-                                        next_matrices=None if nxt is None else nxt[2])
+        if real is not None:
+            # real scenes have tens to hundreds of frames each: a fixed number of views per forward (one graph shape), scene by scene
+            vpf = max(1, int(getattr(cfg, "views_per_forward", 20)))
+            results = [pipeline.infer_scene(model, sd_, cfg, vox, m_, views_per_batch=None if len(sd_.views) <= vpf else vpf)
+                       for sd_, m_ in zip(sds, mats)]
+        else:
+            results = pipeline.infer_scenes(model, sds, cfg, vox, mats, next_scenes=None if nxt is None else nxt[1],
+                                            next_matrices=None if nxt is None else nxt[2])
         for s, scene, preds in zip(chunk, scs, results):
-            gt = synthetic_labels(scene, K, s).to(dev)
+            gt = (torch.from_numpy(scene.labels) if real is not None else synthetic_labels(scene, K, s)).to(dev)
             for j, p in enumerate(preds):
                 acc[j] += torch.stack(metrics.intersection_and_union(p, gt, K, tuple(cfg.test_ignore_label)))
     if world > 1:

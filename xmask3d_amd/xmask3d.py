@@ -111,6 +111,13 @@ class XMASK3d(nn.Module):
                                            test_labels=[[l] for l in cfg.all_label], projection_dim=-1)
         self.clip_head = self.criterion.clip
         self.set_dense_dtype(dense_dtype)
+        # frozen SD / CLIP weights, BPE vocabulary and the empty-prompt conditioning from local files when they are there
+        # (sd_model/sd-v1-3.ckpt, openai/: ldm.py:105-114, clip.py:69-73); seeded random weights + stand-in tokenizer otherwise
+        from . import checkpoint as _ckpt
+
+        self.pretrained_report = None
+        if any(_ckpt.find_pretrained(cfg).values()):
+            _ckpt.load_pretrained(self, cfg)
 
     def set_dense_dtype(self, dense_dtype):
         """frozen SD / CLIP-visual nets hold their weights in the dense compute dtype (fp32 or bf16)"""
