@@ -229,7 +229,8 @@ int xm3d_group_norm_nhwc_apply(const void* x, const void* shift, int32_t shift_b
  *       stats_out (B, groups_out, 2) f64 or NULL: += moments of the bf16 values stored to out (caller zeroes it).
  *       ws: xm3d_conv3x3_ws_bytes(B, cin) bytes of device scratch (the per-(image, channel) affine derived from the moments by a
  *       small kernel in front of the convolution); may be NULL without GroupNorm.
- *   Constraints: H % 8 == 0, W % 32 == 0, cin % 64 == 0, cout % cout_tile == 0, (cout / groups_out) % 4 == 0, 16-byte aligned tensors.
+ *       waves: 0 (choose), 8 or 4 - the workgroup geometry, results do not depend on it.
+ *   Constraints: H % 8 == 0 (waves 8) or H % 4 == 0 (waves 4), W % 32 == 0, cin % 64 == 0, cout % cout_tile == 0, (cout / groups_out) % 4 == 0, 16-byte aligned tensors.
  *   Launched on `stream`, no host synchronisation. */
 int xm3d_conv3x3_cout_tile(int32_t cout);
 int xm3d_conv3x3_pack_weight(const void* w_ohwi, int32_t cout, int32_t cin, int32_t cout_tile, void* packed, void* stream);
@@ -237,7 +238,10 @@ int64_t xm3d_conv3x3_ws_bytes(int64_t B, int32_t cin);
 int xm3d_conv3x3_nhwc(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,
                       const double* gn_stats, const float* gamma, const float* beta, const float* in_shift, int32_t in_shift_bstride,
                       float eps, int32_t groups, int32_t act, const float* bias, int32_t bias_bstride, const void* residual, void* out, double* stats_out,
-                      int32_t groups_out, int32_t upsample, void* ws, void* stream);
+                      int32_t groups_out, int32_t upsample, int32_t waves, void* ws, void* stream);
+/* waves of a workgroup the call above uses when waves = 0: 8 (8 x 32 pixel tile, one workgroup per CU) or 4 (4 x 32 pixel tile, two
+ * workgroups per CU, whose memory-bound prologue / epilogue overlap each other's matrix work) */
+int xm3d_conv3x3_default_waves(int32_t H, int32_t W, int32_t cin, int32_t cout);
 /* GroupNorm moments alone, in the layout the calls above take: stats (B*G*2) f64 <- (sum, sum of squares) of x (+ shift) per
  * (sample, group); x (B, H*W, C) channels-last, dtype 0 = f32 / 1 = bf16; stats is zeroed here. */
 int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,

@@ -21,9 +21,10 @@ def _nhwc(t):
     return t.contiguous(memory_format=torch.channels_last)
 
 
+@pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("B,cin,cout,H,W,ups", [(1, 64, 128, 8, 32, False), (2, 128, 256, 16, 64, False), (1, 192, 128, 24, 32, False),
                                                 (2, 64, 256, 16, 64, True), (1, 128, 512, 8, 96, False), (1, 64, 128, 16, 32, True)])
-def test_conv3x3_plain_is_exact_on_integer_data(dev, B, cin, cout, H, W, ups):
+def test_conv3x3_plain_is_exact_on_integer_data(dev, B, cin, cout, H, W, ups, waves):
     from xmask3d_amd import ops
 
     g = torch.Generator().manual_seed(cin * 7 + cout + H + W)
@@ -33,7 +34,7 @@ def test_conv3x3_plain_is_exact_on_integer_data(dev, B, cin, cout, H, W, ups):
     bias = torch.randint(-3, 4, (cout,), generator=g).float()
     xd = _nhwc(x.to(dev, torch.bfloat16))
     packed, tile = ops.conv3x3_pack_weight(w.to(dev))
-    out = ops.conv3x3(xd, packed, cout, tile, bias=bias.to(dev), upsample=ups)
+    out = ops.conv3x3(xd, packed, cout, tile, bias=bias.to(dev), upsample=ups, waves=waves)
     xin = x.to(dev)
     if ups:
         xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
@@ -43,10 +44,11 @@ def test_conv3x3_plain_is_exact_on_integer_data(dev, B, cin, cout, H, W, ups):
     assert torch.equal(out.float(), ref), (out.float() - ref).abs().max().item()
 
 
+@pytest.mark.parametrize("waves", [8, 4])
 @pytest.mark.parametrize("B,cin,cout,H,W,res,per_sample_bias", [(2, 128, 128, 16, 64, True, False), (1, 256, 256, 8, 32, False, True),
                                                                 (2, 128, 256, 16, 32, False, False), (1, 512, 512, 8, 64, True, True),
                                                                 (3, 320, 640, 8, 32, False, True), (1, 128, 128, 40, 32, True, False), (1, 64, 128, 8, 32, False, False)])
-def test_conv3x3_groupnorm_silu_matches_torch(dev, B, cin, cout, H, W, res, per_sample_bias):
+def test_conv3x3_groupnorm_silu_matches_torch(dev, B, cin, cout, H, W, res, per_sample_bias, waves):
     from xmask3d_amd import ops
 
     g = torch.Generator().manual_seed(cin + cout * 3 + H)
@@ -61,7 +63,7 @@ def test_conv3x3_groupnorm_silu_matches_torch(dev, B, cin, cout, H, W, res, per_
     packed, tile = ops.conv3x3_pack_weight(w)
     stats = ops.gn_stats_of(x, G)
     gs = 32 if (cout // 32) % 4 == 0 else None
-    out = ops.conv3x3(x, packed, cout, tile, bias=bias, gn=(stats, gamma, beta, eps, G), residual=residual, stats_groups=gs)
+    out = ops.conv3x3(x, packed, cout, tile, bias=bias, gn=(stats, gamma, beta, eps, G), residual=residual, stats_groups=gs, waves=waves)
 
     xn = F.silu(F.group_norm(x.float(), G, gamma, beta, eps)).to(torch.bfloat16).float()
     ref = F.conv2d(xn, w.float(), None, padding=1) + bias.view(-1 if per_sample_bias else 1, cout, 1, 1)
@@ -115,7 +117,7 @@ def test_conv3x3_rejects_what_it_cannot_run(dev):
         from xmask3d_amd._lib import check
         out = torch.empty_like(x)
         check(lib().xm3d_conv3x3_nhwc(_ptr(x), 1, 8, 32, 64, _ptr(packed), 128, tile, None, None, None, None, 0, 0.0, 0, 1, None, 0, None, _ptr(out), None, 0, 0,
-                                      None, _stream()), "xm3d_conv3x3_nhwc")
+                                      0, None, _stream()), "xm3d_conv3x3_nhwc")
 
 
 def _module_pair(mod_fn, dev):

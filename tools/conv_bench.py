@@ -46,11 +46,11 @@ for name, cin, cout, H, W in SHAPES:
     stats = ops.gn_stats_of(x, G)
     flop = 2.0 * B * H * W * 9 * cin * cout
 
-    def fused():
-        return ops.conv3x3(x, packed, cout, tile, bias=bias, gn=(stats, gamma, beta, 1e-6, G), residual=res, stats_groups=G if (cout // G) % 4 == 0 else None)
+    def fused(waves=8):
+        return ops.conv3x3(x, packed, cout, tile, bias=bias, gn=(stats, gamma, beta, 1e-6, G), residual=res, stats_groups=G if (cout // G) % 4 == 0 else None, waves=waves)
 
-    def plain():
-        return ops.conv3x3(x, packed, cout, tile, bias=bias)
+    def plain(waves=8):
+        return ops.conv3x3(x, packed, cout, tile, bias=bias, waves=waves)
 
     def chain():  # what the round-2 path runs per convolution: apply pass (statistics known), library conv, bias + residual + stats pass
         y = ops.group_norm(x, G, gb, bb, 1e-6, 1)
@@ -62,9 +62,10 @@ for name, cin, cout, H, W in SHAPES:
 
     with torch.no_grad():
         t_f, t_p, t_c, t_l = timeit(fused, iters), timeit(plain, iters), timeit(chain, iters), timeit(lib_conv, iters)
+        t_f4, t_p4 = timeit(lambda: fused(4), iters), timeit(lambda: plain(4), iters)
         o1, o2 = fused().float(), chain().float()
         err = (o1 - o2).abs().max().item() / o2.abs().max().item()
     print(f"{name:18s} B={B} fused {t_f:8.1f} us {flop / t_f / 1e6:7.1f} TF | plain {t_p:8.1f} us {flop / t_p / 1e6:7.1f} TF | "
-          f"library conv {t_l:8.1f} us {flop / t_l / 1e6:7.1f} TF | round-2 chain {t_c:8.1f} us | fused/chain x{t_c / t_f:.2f} | diff {err:.1e}", flush=True)
+          f"4-wave: fused {t_f4:8.1f} us {flop / t_f4 / 1e6:7.1f} TF plain {t_p4:8.1f} us | library conv {t_l:8.1f} us {flop / t_l / 1e6:7.1f} TF | round-2 chain {t_c:8.1f} us | fused/chain x{t_c / t_f:.2f} | diff {err:.1e}", flush=True)
     del x, w, res, packed
     torch.cuda.empty_cache()

@@ -28,6 +28,8 @@
 //     and the GroupNorm statistics of the result are in-lane sums + one 32-lane reduction per channel quad.
 //   * wave tile: CT = 256: 32 channels x all 256 pixels (8 accumulator tiles); CT = 128: 32 channels x 128 pixels (waves 4 x 2).
 // Bound: MFMA (bf16).  Algorithmic FLOP = 2 * B*H*W * 9*Cin * Cout; bytes = B*H*W*(Cin + Cout [+ Cout residual])*2 + weights.
+#include <type_traits>
+
 #include "common.h"
 
 namespace xm3d {
@@ -38,13 +40,10 @@ typedef __bf16 cv_bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 cv_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned cv_u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CV_TW = 32, CV_TH = 8;                 // output pixel tile (one image)
-constexpr int CV_HW = CV_TW + 2, CV_HH = CV_TH + 2;  // halo tile
-constexpr int CV_HPIX = CV_HW * CV_HH;               // 340 halo pixels
+constexpr int CV_TW = 32;                            // output pixel tile: CV_TW columns x 8 or 4 rows of one image (ConvGeom)
+constexpr int CV_HW = CV_TW + 2;                     // halo tile width
 constexpr int CV_PSTR = 144;                         // bytes per halo pixel: 64 channels bf16 + 16 pad
-constexpr int CV_ASZ = CV_HPIX * CV_PSTR;            // 48,960 bytes per halo buffer
 constexpr int CV_KC = 64;                            // input channels per chunk
-constexpr int CV_ROUNDS = (CV_HPIX * 8 + 511) / 512; // 16-byte pieces per thread and chunk (6; the last round is partial)
 constexpr float CV_LOG2E = 1.4426950408889634f;
 #ifndef CV_ABL
 #define CV_ABL 0  // timing-only ablations (tools/conv_ablate.sh): 1 no weight ring refill, 2 no MFMA, 4 no fragment reads, 8 no chunk barrier, 16 no halo staging
@@ -70,22 +69,41 @@ struct ConvArgs {
     int tiles_x, tiles_y, nct;
 };
 
+// Geometry of a workgroup.  NW = 8: 512 threads, 8 x 32 pixel tile, one workgroup per CU (98 KB of LDS), each wave one 32-channel
+// row block.  NW = 4: 256 threads, 4 x 32 pixel tile, TWO workgroups per CU (59 KB each): the prologue (first halo tile) and the
+// epilogue (residual read, output write - HBM-bound phases without matrix work) of one overlap the main loop of the other; each
+// wave owns CT / 128 row blocks x all 4 pixel rows.
+template <int CT, int NW>
+struct ConvGeom {
+    static constexpr int TH = NW == 8 ? 8 : 4;                         // pixel rows of the tile
+    static constexpr int HPIX = (TH + 2) * CV_HW;                      // halo pixels
+    static constexpr int ASZ = HPIX * CV_PSTR;                         // bytes per halo buffer
+    static constexpr int NTH = NW * 64;                                // threads
+    static constexpr int PR = NTH / 8;                                 // pixels staged per round
+    static constexpr int ROUNDS = (HPIX + PR - 1) / PR;                // 16-byte pieces per thread and chunk (last round partial)
+    static constexpr int MB = NW == 8 ? 1 : CT / 128;                  // 32-channel row blocks per wave
+    static constexpr int NT = NW == 8 ? (CT == 256 ? 8 : 4) : 4;       // 32-pixel tiles (rows of the pixel tile) per wave
+    static constexpr int NG = MB * NT / 4;                             // groups of 4 MFMAs per k-step
+    static constexpr int D = MB == 2 ? 4 : CV_WRING;                   // weight ring depth (k-steps in flight per row block)
+    static constexpr int LDS = 2 * ASZ + 16;
+    static_assert(ROUNDS <= 8 && 36 % D == 0, "staging schedule / ring depth");
+};
+
 // MODE 0: x is the operand as it stands (plain convolution); MODE 2: operand = SiLU(GroupNorm(x)).
 // UPS: x has half the resolution, the operand is its nearest-neighbour 2x upsampling (ldm's Upsample -> conv).
-template <int CT, int MODE, bool UPS>
-__global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
-    constexpr int NT = CT == 256 ? 8 : 4;  // 32-pixel tiles (= rows of the pixel tile) per wave
-    constexpr int NG = NT / 4;             // groups of 4 MFMAs per k-step
+template <int CT, int MODE, bool UPS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
+    using G = ConvGeom<CT, NW>;
+    constexpr int TH = G::TH, HPIX = G::HPIX, ASZ = G::ASZ, PR = G::PR, ROUNDS = G::ROUNDS, MB = G::MB, NT = G::NT, NG = G::NG, D = G::D;
     constexpr int NGRP = 36 * NG;          // groups per chunk
-    constexpr int D = CV_WRING;            // weight ring depth (k-steps in flight)
     constexpr int ROWB = CV_HW * CV_PSTR;  // bytes per halo row
     extern __shared__ __attribute__((aligned(16))) char smem[];
     char* const abuf = smem;  // 2 halo buffers, then a 16-byte dump slot
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wb = CT == 256 ? wave : wave >> 1;          // 32-channel row block of the tile owned by this wave
-    const int nbase = CT == 256 ? 0 : 4 * (wave & 1);     // first pixel row of this wave
+    const int wb0 = NW == 8 ? (CT == 256 ? wave : wave >> 1) : wave * MB;  // first 32-channel row block of this wave
+    const int nbase = (NW == 8 && CT == 128) ? 4 * (wave & 1) : 0;          // first pixel row of this wave
     const int l31 = lane & 31, h = lane >> 5;
 
     // XCD-aware tile order (speed only): blocks i and i + 8 share an XCD's L2 - give each XCD a contiguous run of tiles
@@ -107,28 +125,31 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
     const int nch = cin / CV_KC;
     const int nk = nch * 36;  // k-steps
 
-    // ---- weight stream of this wave: 1 KiB (64 lanes x 16 bytes = one A fragment) per k-step, contiguous
-    const char* const wstream = reinterpret_cast<const char*>(a.wp) + (int64_t(ct) * (CT / 32) + wb) * nk * 1024 + lane * 16;
-    cv_bf16x8 wr[D];
+    // ---- weight streams of this wave: per row block 1 KiB (64 lanes x 16 bytes = one A fragment) per k-step, contiguous
+    const char* const wstream = reinterpret_cast<const char*>(a.wp) + (int64_t(ct) * (CT / 32) + wb0) * nk * 1024 + lane * 16;
+    cv_bf16x8 wr[D][MB];
 #pragma unroll
-    for (int i = 0; i < D; ++i) wr[i] = *reinterpret_cast<const cv_bf16x8*>(wstream + int64_t(i < nk ? i : nk - 1) * 1024);
+    for (int i = 0; i < D; ++i)
+#pragma unroll
+        for (int m = 0; m < MB; ++m)
+            wr[i][m] = *reinterpret_cast<const cv_bf16x8*>(wstream + (int64_t(m) * nk + (i < nk ? i : nk - 1)) * 1024);
 
-    // ---- halo staging: thread owns 16-byte piece (pixel prow + 64 r, channels 8 kc .. 8 kc + 7) of every round r
+    // ---- halo staging: thread owns 16-byte piece (pixel prow + PR r, channels 8 kc .. 8 kc + 7) of every round r
     const int kc = tid & 7, prow = tid >> 3;
-    int aoff[CV_ROUNDS];  // element offset of the piece's source inside the image; -1: outside the image (zero padding)
+    int aoff[ROUNDS];  // element offset of the piece's source inside the image; -1: outside the image (zero padding)
 #pragma unroll
-    for (int r = 0; r < CV_ROUNDS; ++r) {
-        const int p = prow + 64 * r;
+    for (int r = 0; r < ROUNDS; ++r) {
+        const int p = prow + PR * r;
         const int hy = p / CV_HW, hx = p - hy * CV_HW;
-        const int gy = ty * CV_TH - 1 + hy, gx = tx * CV_TW - 1 + hx;
-        const bool inb = p < CV_HPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
+        const int gy = ty * TH - 1 + hy, gx = tx * CV_TW - 1 + hx;
+        const bool inb = p < HPIX && gy >= 0 && gy < H && gx >= 0 && gx < W;
         const int sy = UPS ? gy >> 1 : gy, sx = UPS ? gx >> 1 : gx;
         aoff[r] = inb ? (sy * Wi + sx) * cin + kc * 8 : -1;
     }
-    const unsigned a_wr = unsigned(prow) * CV_PSTR + kc * 16;  // + r * 64 * CV_PSTR
+    const unsigned a_wr = unsigned(prow) * CV_PSTR + kc * 16;  // + r * PR * CV_PSTR
 
     // GroupNorm affine of the chunk being staged, y = x * sc + sh: per-(image, channel) table written by k_gn_affine just before
-    // this launch.  Loaded for the chunk after next in stage 7, when the last piece of the next one has been normalised.
+    // this launch.  Loaded for the chunk after next in stage 8, when the last piece of the next one has been normalised.
     float sc[8], sh[8];
     const float* const aff = MODE != 0 ? a.affine + (int64_t(b) * cin + kc * 8) * 2 : nullptr;
     auto gn_coeffs = [&](int c0) __attribute__((always_inline)) {
@@ -159,8 +180,8 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
     };
     auto a_store = [&](int r, cv_u32x4 o, char* dst) __attribute__((always_inline)) {
         if (aoff[r] < 0) o = cv_u32x4{0u, 0u, 0u, 0u};  // zero padding applies to the activated operand
-        char* p = dst + a_wr + r * 64 * CV_PSTR;
-        if (r == CV_ROUNDS - 1 && prow + 64 * r >= CV_HPIX) p = smem + 2 * CV_ASZ;  // dump slot (16 bytes)
+        char* p = dst + a_wr + r * PR * CV_PSTR;
+        if (r == ROUNDS - 1 && prow + PR * r >= HPIX) p = smem + 2 * ASZ;  // dump slot (16 bytes)
         *reinterpret_cast<cv_u32x4*>(p) = o;
     };
     auto a_write = [&](int r, cv_u32x4 raw, char* dst) __attribute__((always_inline)) {
@@ -172,35 +193,40 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
     // pixels (B operand): halo pixel (nbase + n + ky) * 34 + l31 + kx, 16-byte granule 2 ks + h
     const unsigned xbase = unsigned(nbase * CV_HW + l31) * CV_PSTR + h * 16;
 
-    cv_f32x16 acc[NT];
+    cv_f32x16 acc[MB][NT];
 #pragma unroll
-    for (int n = 0; n < NT; ++n)
+    for (int m = 0; m < MB; ++m)
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[m][n][i] = 0.f;
 
     // ---- prologue: chunk 0 halo
     gn_coeffs(0);
     if (!(CV_ABL & 64))
 #pragma unroll
-        for (int r = 0; r < CV_ROUNDS; ++r) a_write(r, a_load(r, 0), abuf);
+        for (int r = 0; r < ROUNDS; ++r) a_write(r, a_load(r, 0), abuf);
     gn_coeffs((nch > 1 ? 1 : 0) * CV_KC);  // chunk 1 is staged during chunk 0
     __syncthreads();
 
     unsigned acur = 0;  // byte offset of the current halo buffer
-    for (int c = 0; c < nch; ++c) {
-        // the chunk staged during this one; past the end the last chunk is staged again into the buffer nobody reads any more
-        // (keeps the loop free of branches)
-        const int c1 = (c + 1 < nch ? c + 1 : c) * CV_KC;
+    // one chunk = 36 k-steps, fully unrolled (tap offsets are immediates, ring slots static).  STAGE: the next chunk's halo tile is
+    // staged beside the MFMAs (every chunk but the last)
+    auto chunk = [&](int c, auto stage_tag) __attribute__((always_inline)) {
+        constexpr bool STAGE = decltype(stage_tag)::value;
+        const int c1 = (c + 1) * CV_KC;
         const int c2 = (c + 2 < nch ? c + 2 : nch - 1) * CV_KC;
-        char* const anext = abuf + (acur ^ unsigned(CV_ASZ));
+        char* const anext = abuf + (acur ^ unsigned(ASZ));
         const char* const xl = abuf + acur + xbase;
         const int kbase = c * 36;
         cv_u32x4 rawq[2];
         cv_bf16x8 xf[2][4];
-        // fragments of group g+1 are requested before the MFMAs of group g (register double buffer); the order is pinned with
-        // sched_barrier: hipcc's own schedule issues each read right in front of its consumer and waits lgkmcnt(0) every 4 MFMAs
-        auto x_load = [&](int g, int s) __attribute__((always_inline)) {
-            const int J = g / NG, half = g % NG, t = J / 4, ks = J % 4, ky = t / 3, kx = t % 3;
+        // The B fragments ("x-sets" of 4 pixel tiles) of set s+1 are requested before the MFMAs of set s (register double buffer); the
+        // order is pinned with sched_barrier: hipcc's own schedule issues each read right in front of its consumer and waits
+        // lgkmcnt(0) every 4 MFMAs.  NT = 8: a k-step has two x-sets (pixel rows 0-3 / 4-7); MB = 2: both row blocks share one.
+        constexpr int XS = NT == 8 ? 72 : 36;  // x-sets per chunk
+        auto x_load = [&](int xs, int s) __attribute__((always_inline)) {
+            const int J = NT == 8 ? xs / 2 : xs, half = NT == 8 ? xs % 2 : 0, t = J / 4, ks = J % 4, ky = t / 3, kx = t % 3;
 #pragma unroll
             for (int n = 0; n < 4; ++n)
                 xf[s][n] = *reinterpret_cast<const cv_bf16x8*>(xl + (half * 4 + n + ky) * ROWB + kx * CV_PSTR + ks * 32);
@@ -208,19 +234,21 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
         x_load(0, 0);
 #pragma unroll
         for (int g = 0; g < NGRP; ++g) {
-            const int J = g / NG, half = g % NG, t = J / 4, ks = J % 4;
+            const int J = g / NG, sub = g % NG, t = J / 4, ks = J % 4;
+            const int xs = NT == 8 ? g : J, mb = MB == 2 ? sub : 0, half = NT == 8 ? sub : 0;
+            const bool first_of_set = NT == 8 || sub == 0;
             __builtin_amdgcn_sched_barrier(0);
             // piece t of the next chunk's halo: requested at the top of stage t, normalised and written during stage t + 1
-            if (ks == 0 && half == 0 && t < CV_ROUNDS && !(CV_ABL & 16)) rawq[t & 1] = a_load(t, c1);
-            if (g + 1 < NGRP && !(CV_ABL & 4)) x_load(g + 1, (g + 1) & 1);
+            if (STAGE && ks == 0 && sub == 0 && t < ROUNDS && !(CV_ABL & 16)) rawq[t & 1] = a_load(t, c1);
+            if (first_of_set && xs + 1 < XS && !(CV_ABL & 4)) x_load(xs + 1, (xs + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (t >= 1 && t <= CV_ROUNDS && !(CV_ABL & 16)) {
+            if (STAGE && t >= 1 && t <= ROUNDS && !(CV_ABL & 16)) {
                 // the piece requested in the previous stage: one channel pair per quarter of the stage's groups, beside that
                 // group's MFMAs, the store with the last one - ~18 vector instructions per 4 MFMAs instead of ~75 in one place.
                 // The asm ties the arithmetic (no side effects) to this point: it would otherwise be scheduled directly behind
                 // the load, in front of a wait for it
                 constexpr int SG = 4 * NG;  // groups per stage
-                const int sg = ks * NG + half;
+                const int sg = ks * NG + sub;
                 cv_u32x4& raw = rawq[(t - 1) & 1];
 #pragma unroll
                 for (int i = 0; i < 4; ++i)
@@ -230,16 +258,18 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
                         if (i == 3) a_store(t - 1, raw, anext);
                     }
             }
-            if (t == 7 && ks == 0 && half == 0) gn_coeffs(c2);  // affine of the chunk staged during the NEXT chunk
+            if (STAGE && t == 8 && ks == 0 && sub == 0) gn_coeffs(c2);  // affine of the chunk staged during the NEXT chunk
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
-                if (CV_ABL & 2) asm volatile("" ::"v"(wr[J % D]), "v"(xf[g & 1][n]));
-                else acc[half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[J % D], xf[g & 1][n], acc[half * 4 + n], 0, 0, 0);
+                if (CV_ABL & 2) asm volatile("" ::"v"(wr[J % D][mb]), "v"(xf[xs & 1][n]));
+                else acc[mb][half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[J % D][mb], xf[xs & 1][n], acc[mb][half * 4 + n], 0, 0, 0);
             }
-            if (half == NG - 1 && !(CV_ABL & 1)) {  // the ring slot is free: request the fragment of k-step J + D
+            if (sub == NG - 1 && !(CV_ABL & 1)) {  // the ring slot is free: request the fragments of k-step J + D
                 __builtin_amdgcn_sched_barrier(0);
                 const int jn = kbase + J + D;
-                wr[J % D] = *reinterpret_cast<const cv_bf16x8*>(wstream + int64_t(jn < nk ? jn : nk - 1) * 1024);
+#pragma unroll
+                for (int m = 0; m < MB; ++m)
+                    wr[J % D][m] = *reinterpret_cast<const cv_bf16x8*>(wstream + (int64_t(m) * nk + (jn < nk ? jn : nk - 1)) * 1024);
             }
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -248,8 +278,10 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         if (!(CV_ABL & 8)) __builtin_amdgcn_s_barrier();
         asm volatile("" ::: "memory");
-        acur ^= unsigned(CV_ASZ);
-    }
+        acur ^= unsigned(ASZ);
+    };
+    for (int c = 0; c + 1 < nch; ++c) chunk(c, std::true_type{});
+    chunk(nch - 1, std::false_type{});
 
     // ---- epilogue: + bias (+ residual) -> bf16, GroupNorm statistics of the stored values
     float* const sred = reinterpret_cast<float*>(smem);  // per-group (sum, sumsq) of this tile
@@ -265,58 +297,63 @@ __global__ __launch_bounds__(512, 2) void k_conv3x3(const ConvArgs a) {
     if ((CV_ABL & 32) && a.B > 0) {  // timing only: no epilogue (one store keeps the accumulators alive)
         float t = 0.f;
 #pragma unroll
-        for (int n = 0; n < NT; ++n) t += acc[n][0];
+        for (int m = 0; m < MB; ++m)
+#pragma unroll
+            for (int n = 0; n < NT; ++n) t += acc[m][n][0];
         if (t == 123.456f) a.out[0] = (__bf16)t;
     } else {
-        // the packed weights put channel 16 h + i of the wave's 32 on MFMA row (i & 3) + 8 (i >> 2) + 4 h, i.e. in accumulator
-        // register i of lane (pixel, h): a lane owns 16 CONSECUTIVE channels of one pixel = two 16-byte accesses
-        const int chl = wb * 32 + 16 * h;  // + i : channel inside the tile
-        float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
-        float4 bq[4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) bq[q] = bias ? *reinterpret_cast<const float4*>(bias + chl + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int m = 0; m < MB; ++m) {
+            // the packed weights put channel 16 h + i of a row block's 32 on MFMA row (i & 3) + 8 (i >> 2) + 4 h, i.e. in accumulator
+            // register i of lane (pixel, h): a lane owns 16 CONSECUTIVE channels of one pixel = two 16-byte accesses
+            const int chl = (wb0 + m) * 32 + 16 * h;  // + i : channel inside the tile
+            float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
+            float4 bq[4];
 #pragma unroll
-        for (int n = 0; n < NT; ++n) {
-            const int y = ty * CV_TH + nbase + n, px = tx * CV_TW + l31;
-            const int64_t o = ((int64_t(b) * H + y) * W + px) * a.cout + ct * CT + chl;
-            uint4 rr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
-            if (a.residual) {
-                rr[0] = *reinterpret_cast<const uint4*>(a.residual + o);
-                rr[1] = *reinterpret_cast<const uint4*>(a.residual + o + 8);
-            }
-            const unsigned rw[8] = {rr[0].x, rr[0].y, rr[0].z, rr[0].w, rr[1].x, rr[1].y, rr[1].z, rr[1].w};
-            cv_bf16x8 pk[2];
+            for (int q = 0; q < 4; ++q) bq[q] = bias ? *reinterpret_cast<const float4*>(bias + chl + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const float v[4] = {acc[n][4 * q] + bq[q].x + __uint_as_float(rw[2 * q] << 16),
-                                    acc[n][4 * q + 1] + bq[q].y + __uint_as_float(rw[2 * q] & 0xFFFF0000u),
-                                    acc[n][4 * q + 2] + bq[q].z + __uint_as_float(rw[2 * q + 1] << 16),
-                                    acc[n][4 * q + 3] + bq[q].w + __uint_as_float(rw[2 * q + 1] & 0xFFFF0000u)};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const __bf16 r = (__bf16)v[j];
-                    pk[q >> 1][(q & 1) * 4 + j] = r;
-                    const float vr = (float)r;
-                    gs[q] += vr;
-                    gq[q] = fmaf(vr, vr, gq[q]);
+            for (int n = 0; n < NT; ++n) {
+                const int y = ty * TH + nbase + n, px = tx * CV_TW + l31;
+                const int64_t o = ((int64_t(b) * H + y) * W + px) * a.cout + ct * CT + chl;
+                uint4 rr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+                if (a.residual) {
+                    rr[0] = *reinterpret_cast<const uint4*>(a.residual + o);
+                    rr[1] = *reinterpret_cast<const uint4*>(a.residual + o + 8);
                 }
-            }
-            *reinterpret_cast<cv_bf16x8*>(a.out + o) = pk[0];
-            *reinterpret_cast<cv_bf16x8*>(a.out + o + 8) = pk[1];
-        }
-        if (want_stats) {
+                const unsigned rw[8] = {rr[0].x, rr[0].y, rr[0].z, rr[0].w, rr[1].x, rr[1].y, rr[1].z, rr[1].w};
+                cv_bf16x8 pk[2];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                float s = gs[q], ss = gq[q];
+                for (int q = 0; q < 4; ++q) {
+                    const float v[4] = {acc[m][n][4 * q] + bq[q].x + __uint_as_float(rw[2 * q] << 16),
+                                        acc[m][n][4 * q + 1] + bq[q].y + __uint_as_float(rw[2 * q] & 0xFFFF0000u),
+                                        acc[m][n][4 * q + 2] + bq[q].z + __uint_as_float(rw[2 * q + 1] << 16),
+                                        acc[m][n][4 * q + 3] + bq[q].w + __uint_as_float(rw[2 * q + 1] & 0xFFFF0000u)};
 #pragma unroll
-                for (int off = 16; off > 0; off >>= 1) {
-                    s += __shfl_xor(s, off);
-                    ss += __shfl_xor(ss, off);
+                    for (int j = 0; j < 4; ++j) {
+                        const __bf16 r = (__bf16)v[j];
+                        pk[q >> 1][(q & 1) * 4 + j] = r;
+                        const float vr = (float)r;
+                        gs[q] += vr;
+                        gq[q] = fmaf(vr, vr, gq[q]);
+                    }
                 }
-                if (l31 == 0) {
-                    const int gl = (ct * CT + chl + 4 * q) / cg_out - g_first;
-                    atomicAdd(&sred[2 * gl], s);
-                    atomicAdd(&sred[2 * gl + 1], ss);
+                *reinterpret_cast<cv_bf16x8*>(a.out + o) = pk[0];
+                *reinterpret_cast<cv_bf16x8*>(a.out + o + 8) = pk[1];
+            }
+            if (want_stats) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float s = gs[q], ss = gq[q];
+#pragma unroll
+                    for (int off = 16; off > 0; off >>= 1) {
+                        s += __shfl_xor(s, off);
+                        ss += __shfl_xor(ss, off);
+                    }
+                    if (l31 == 0) {
+                        const int gl = (ct * CT + chl + 4 * q) / cg_out - g_first;
+                        atomicAdd(&sred[2 * gl], s);
+                        atomicAdd(&sred[2 * gl + 1], ss);
+                    }
                 }
             }
         }
@@ -370,18 +407,24 @@ __global__ void k_gn_affine(const double* __restrict__ stats, const float* __res
     o[8] = beta[c] + ((in_shift ? in_shift[int64_t(b) * in_shift_bstride + c] : 0.f) - float(m)) * scale;
 }
 
-template <int CT, int MODE, bool UPS>
+template <int CT, int MODE, bool UPS, int NW>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
-    constexpr int LDS = 2 * CV_ASZ + 16;
+    using G = ConvGeom<CT, NW>;
     static bool configured = false;
     if (!configured) {
-        XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CT, MODE, UPS>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
+        XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CT, MODE, UPS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
         configured = true;
     }
     const int grid = a.B * a.tiles_y * a.tiles_x * a.nct;
-    hipLaunchKernelGGL((k_conv3x3<CT, MODE, UPS>), dim3(grid), dim3(512), LDS, s, a);
+    hipLaunchKernelGGL((k_conv3x3<CT, MODE, UPS, NW>), dim3(grid), dim3(G::NTH), G::LDS, s, a);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
+}
+
+template <int CT, int NW>
+static int dispatch_conv(const ConvArgs& a, bool gn, bool upsample, hipStream_t s) {
+    if (gn) return launch_conv<CT, 2, false, NW>(a, s);
+    return upsample ? launch_conv<CT, 0, true, NW>(a, s) : launch_conv<CT, 0, false, NW>(a, s);
 }
 
 }  // namespace xm3d
@@ -402,15 +445,28 @@ extern "C" int xm3d_conv3x3_pack_weight(const void* w_ohwi, int cout, int cin, i
     return XM3D_OK;
 }
 
+// workgroup geometry when the caller does not choose (waves = 0); see ConvGeom.  Measured on MI355X, 20 views (tools/conv_bench.py)
+extern "C" int xm3d_conv3x3_default_waves(int H, int W, int cin, int cout) {
+    (void)W;
+    (void)cout;
+    if (H % 8 != 0) return 4;
+    // VAE shapes (cin 128 .. 512 at 64^2 .. 512^2): 2 - 14 % faster with two 4-wave workgroups per CU; the UNet's cin >= 640 at 32^2
+    // (few tiles per CU, long K loop): 3 - 4 % faster with one 8-wave workgroup
+    return cin <= 512 ? 4 : 8;
+}
+
 extern "C" int64_t xm3d_conv3x3_ws_bytes(int64_t B, int32_t cin) { return B > 0 && cin > 0 ? B * int64_t(cin) * 2 * int64_t(sizeof(float)) : 0; }
 
 extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin, const void* wpacked, int cout, int cout_tile,
                                  const double* gn_stats, const float* gamma, const float* beta, const float* in_shift,
                                  int in_shift_bstride, float eps, int groups, int act, const float* bias, int bias_bstride, const void* residual, void* out, double* stats_out,
-                                 int groups_out, int upsample, void* ws, void* stream) {
+                                 int groups_out, int upsample, int waves, void* ws, void* stream) {
     XM3D_REQUIRE(x && wpacked && out, "conv3x3_nhwc: null pointer");
-    XM3D_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && H % CV_TH == 0 && W % CV_TW == 0,
-                 "conv3x3_nhwc: output %dx%d is not a multiple of the %dx%d pixel tile", H, W, CV_TH, CV_TW);
+    XM3D_REQUIRE(waves == 0 || waves == 4 || waves == 8, "conv3x3_nhwc: waves must be 0 (auto), 4 or 8");
+    if (waves == 0) waves = xm3d_conv3x3_default_waves(H, W, cin, cout);
+    const int TH = waves == 8 ? 8 : 4;
+    XM3D_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && H % TH == 0 && W % CV_TW == 0,
+                 "conv3x3_nhwc: output %dx%d is not a multiple of the %dx%d pixel tile", H, W, TH, CV_TW);
     XM3D_REQUIRE(cin > 0 && cin % CV_KC == 0, "conv3x3_nhwc: cin %d is not a multiple of %d", cin, CV_KC);
     XM3D_REQUIRE((cout_tile == 128 || cout_tile == 256) && cout > 0 && cout % cout_tile == 0, "conv3x3_nhwc: cout %d / tile %d unsupported",
                  cout, cout_tile);
@@ -459,12 +515,8 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
     a.groups_out = stats_out ? groups_out : 1;
     a.cg_out = stats_out ? cout / groups_out : cout;
     a.tiles_x = W / CV_TW;
-    a.tiles_y = H / CV_TH;
+    a.tiles_y = H / TH;
     a.nct = cout / cout_tile;
-    if (cout_tile == 256) {
-        if (gn) return launch_conv<256, 2, false>(a, s);
-        return upsample ? launch_conv<256, 0, true>(a, s) : launch_conv<256, 0, false>(a, s);
-    }
-    if (gn) return launch_conv<128, 2, false>(a, s);
-    return upsample ? launch_conv<128, 0, true>(a, s) : launch_conv<128, 0, false>(a, s);
+    if (cout_tile == 256) return waves == 8 ? dispatch_conv<256, 8>(a, gn, upsample != 0, s) : dispatch_conv<256, 4>(a, gn, upsample != 0, s);
+    return waves == 8 ? dispatch_conv<128, 8>(a, gn, upsample != 0, s) : dispatch_conv<128, 4>(a, gn, upsample != 0, s);
 }

@@ -487,13 +487,13 @@ def gn_stats_of(x, num_groups=32, shift=None):
 
 
 def conv3x3_supported(x, cout, upsample=False):
-    """shapes xm3d_conv3x3_nhwc takes: channels-last bf16, output H % 8 == 0, W % 32 == 0, cin % 64 == 0, cout % 128 == 0"""
+    """shapes xm3d_conv3x3_nhwc takes: channels-last bf16, output H % 4 == 0, W % 32 == 0, cin % 64 == 0, cout % 128 == 0"""
     if not (is_nhwc(x) and x.dtype == torch.bfloat16):
         return False
     _, cin, H, W = x.shape
     if upsample:
         H, W = 2 * H, 2 * W
-    return H % 8 == 0 and W % 32 == 0 and cin % 64 == 0 and cout % 128 == 0
+    return H % 4 == 0 and W % 32 == 0 and cin % 64 == 0 and cout % 128 == 0
 
 
 def conv3x3_pack_weight(weight):
@@ -508,13 +508,14 @@ def conv3x3_pack_weight(weight):
     return packed, tile
 
 
-def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_groups=None, upsample=False, in_shift=None):
+def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_groups=None, upsample=False, in_shift=None, waves=0):
     """out = conv3x3(SiLU(GroupNorm(x))) + bias (+ residual), channels-last bf16 (B, C, H, W) in and out.
     packed, tile: conv3x3_pack_weight(weight).  gn: None (plain convolution) or (stats f64 (B*G*2), gamma f32 (cin), beta f32 (cin),
     eps, G).  bias: None, (cout,) or (B, cout) f32.  residual: tensor like the output.  stats_groups: G of the GroupNorm that reads
     the result next - its moments are accumulated in the epilogue and attached to the returned tensor (gn_stats_of picks them up).
     upsample: x is nearest-upsampled 2x first (plain convolution only).
-    in_shift: (cin,) or (B, cin) f32 added to x in front of the GroupNorm (gn's moments must be those of x + in_shift)."""
+    in_shift: (cin,) or (B, cin) f32 added to x in front of the GroupNorm (gn's moments must be those of x + in_shift).
+    waves: 0 = the library's choice, 8 / 4 = workgroup geometry (same results)."""
     if not conv3x3_supported(x, cout, upsample):
         raise TypeError(f"conv3x3: unsupported input {tuple(x.shape)} {x.dtype} (channels-last bf16, H % 8, W % 32, cin % 64, cout % 128)")
     B, cin, H, W = x.shape
@@ -548,7 +549,7 @@ def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_grou
         ws = torch.empty(B * cin * 2, dtype=torch.float32, device=x.device)
     check(lib().xm3d_conv3x3_nhwc(_ptr(x), B, H, W, cin, _ptr(packed), cout, tile, _ptr(stats_in), _ptr(gamma), _ptr(beta), _ptr(in_shift), sstride,
                                   float(eps), int(G), act, _ptr(bias), bstride, _ptr(residual), _ptr(out), _ptr(stats_out), int(stats_groups or 0), int(bool(upsample)),
-                                  _ptr(ws), _stream()), "xm3d_conv3x3_nhwc")
+                                  int(waves), _ptr(ws), _stream()), "xm3d_conv3x3_nhwc")
     if stats_out is not None:
         out._xm3d_gn_stats = (stats_out, int(stats_groups), out.data_ptr())
     return out
