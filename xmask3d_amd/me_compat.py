@@ -114,9 +114,18 @@ class _BatchNormFn(torch.autograd.Function):
         x, weight, mean, invstd, tot = ctx.saved_tensors
         gy = gy.contiguous()
         sums = ops.bn_bwd_reduce(gy, x, mean, invstd)
+        local = None
         if ctx.group is not None:
+            # the input gradient needs the sums over ALL ranks' rows (the statistics couple them); the affine gradients must stay
+            # this rank's own share - DDP averages parameter gradients over the ranks, and torch.nn.SyncBatchNorm does the same.
+            # (Taking them from the all-reduced sums made every rank hold the global value: world x the intended gradient -
+            # found by tests/test_gpu_distributed.py against a single process on the union of the data.)
+            local = sums.clone()
             dist.all_reduce(sums, group=None if ctx.group is True else ctx.group)
         gx, gw, gb = ops.bn_bwd_apply(gy, x, mean, invstd, weight, sums, tot, need_wb=weight is not None or ctx.has_bias)
+        if local is not None and gw is not None:
+            c = x.shape[1]
+            gb, gw = local[:c].float(), local[c:].float()
         return gx, (gw if weight is not None else None), (gb if ctx.has_bias else None), None, None, None, None, None, None
 
 
