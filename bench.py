@@ -273,7 +273,7 @@ def main():
                          "\"train\" (fp32 as the reference trains, plus a bf16-frozen-nets run); 0 = skip")
     ap.add_argument("--train-deadline", type=int, default=300,
                     help="seconds after which a training leg that has not finished is abandoned (the inference line is printed regardless)")
-    ap.add_argument("--fp32-steps", type=int, default=4, help="inference steps of the fp32 configuration reported under \"fp32\" (0 = skip)")
+    ap.add_argument("--fp32-steps", type=int, default=20, help="inference steps of the fp32 configuration reported under \"fp32\" (0 = skip)")
     ap.add_argument("--scene-pool", type=int, default=8,
                     help="distinct seeded scenes the timed loop cycles through (8 = two different 4-scene groups alternate)")
     ap.add_argument("--nchw", action="store_true", help="keep NCHW activations in the frozen conv nets (default: channels-last)")
@@ -424,15 +424,27 @@ def main():
     # the same pipeline with every net in fp32 (the reference's arithmetic; BASELINE config 2 names bf16, hence not `value`)
     fp32 = None
     if args.dtype == "bf16" and args.fp32_steps > 0 and graphed:
-        # one scene (5 views) per forward: the shipped MIOpen find-db covers the fp32 convolutions at that batch (20-view fp32
-        # shapes would each trigger a find at capture time: minutes of set-up for a secondary number)
+        # the SAME schedule as the headline number (G scenes per forward, the same number of timed steps): the shipped MIOpen
+        # find-db covers the fp32 NHWC convolutions at 20 views since round 3 (tools/tune_miopen.py 20 with XM3D_TUNE_DTYPE=fp32).
+        # This is the configuration inside north_star's 1e-3 on the per-point logits (tests/test_gpu_bench_parity.py).
         m32 = pipeline.make_inference_model(cpu_model, dev, torch.float32, channels_last=not args.nchw, graphs=True)
-        capture(m32, args.fp32_steps, 1)
-        run(m32, 1, 1)
-        dt32 = timed(m32, args.fp32_steps, 1)
+        capture(m32, args.fp32_steps, G)
+        run(m32, G, G)
+        dt32 = timed(m32, args.fp32_steps, G)
+        vb32 = len(sd.views) * G
+        b32 = pipeline.build_scene_batch(sd, [i % len(sd.views) for i in range(vb32)], voxelizer, [np.diag([50.0, 50.0, 50.0, 1.0])] * vb32)
+        with torch.no_grad():
+            _, cond32, _ = m32.encode_3d(b32["sinput"], b32["inds_reconstruct"], vb32)
+            dense32_ms = event_ms(lambda: m32._dense_graphed(b32["img"], cond32), 3) / vb32
         fp32 = {"value": world * args.fp32_steps / dt32, "unit": "scenes/s", "ms_per_step": dt32 / args.fp32_steps * 1e3, "steps": args.fp32_steps,
-                "scenes_per_forward": 1,
-                "dtype": "f32 everywhere (sparse 3D on the bf16x3 split-operand MFMA kernel, f32 accumulate)"}
+                "scenes_per_forward": G,
+                "dtype": "f32 everywhere (sparse 3D on the bf16x3 split-operand MFMA kernel, f32 accumulate; softmax attention = two library "
+                         "GEMMs around an aten softmax)",
+                "roofline_dense_stage": {"bound": "mfma", "achieved": DENSE_TFLOP_PER_VIEW_MIN / (dense32_ms * 1e-3), "peak": FP32_MFMA_PEAK_TF,
+                                         "unit": "TFLOP/s", "frac": DENSE_TFLOP_PER_VIEW_MIN / (dense32_ms * 1e-3) / FP32_MFMA_PEAK_TF,
+                                         "ms_per_view": dense32_ms, "views_per_forward": vb32,
+                                         "scope": "dense 2D branch per view in f32 (library convolutions / GEMMs on the f32 matrix path)"}}
+        del b32, cond32
         del m32
         torch.cuda.empty_cache()
         log(f"fp32 configuration: {fp32['value']:.2f} scenes/s")

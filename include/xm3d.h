@@ -221,7 +221,8 @@ int xm3d_group_norm_nhwc_apply(const void* x, const void* shift, int32_t shift_b
  *   xm3d_conv3x3_pack_weight      : w_ohwi (cout, 3, 3, cin) bf16 (= Conv2d.weight.permute(0,2,3,1)) -> packed (same byte count):
  *                                   per (cout tile, 32-row block) one contiguous stream of MFMA A fragments, 1 KiB per k-step
  *   xm3d_conv3x3_nhwc             : x (B, H>>upsample, W>>upsample, cin) bf16; out / residual (B, H, W, cout) bf16.
- *       gn_stats (B, groups, 2) f64 sum / sum of squares of x over each (sample, group), gamma / beta (cin) f32, act = 1 (SiLU);
+ *       gn_stats (B, groups, 2) f64 sum / sum of squares of x over each (sample, group), gamma / beta (cin) f32, act = 1 (SiLU) or
+ *       2 (ReLU: detectron2's GroupNorm BottleneckBlock of the projection backbone, backbone/feature_extractor.py:20-60);
  *       in_shift (cin) f32 with in_shift_bstride 0, or (B, cin) with in_shift_bstride = cin, or NULL: the GroupNorm input is x + in_shift
  *       (a convolution bias the producer of x left to its consumer) and gn_stats are the moments of that sum.
  *       gn_stats NULL (act 0): plain convolution of x; upsample = 1 (plain only): x is first nearest-upsampled 2x (ldm Upsample).

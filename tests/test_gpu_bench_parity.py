@@ -174,3 +174,33 @@ def test_bench_configuration_votes_match_fp32_reference_path(dev, setup):
             print(f"[votes {name}] agreement {agree:.4f}")
             # 3D-only labels depend on the fp32 sparse nets alone; fused/2D labels carry the bf16 budget of the dense branch
             assert agree > (0.9999 if name == "3d" else 0.97), (name, agree)
+
+
+@pytest.mark.parametrize("name", ["xmask3d_scannet_B12N7", "xmask3d_scannet_B170N30"])
+def test_other_benchmark_configs_match_oracle_per_stage(dev, name):
+    """BASELINE.json configs 4 and 5 (12 base / 7 novel classes; the 200-class ScanNet200 head, 170 / 30) through the same
+    per-stage comparison against the CPU oracle as B15N4 above, in the fp32 configuration (north_star's 1e-3 on the per-point
+    logits) - not only shapes and ranges."""
+    from xmask3d_amd import pipeline, synthetic
+    from xmask3d_amd.config import load_cfg_from_cfg_file
+    from xmask3d_amd.xmask3d import XMASK3d
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cfg = load_cfg_from_cfg_file(os.path.join(root, "configs", name + ".yaml"))
+    torch.manual_seed(cfg.manual_seed)
+    cpu = XMASK3d(cfg).eval()
+    scene = synthetic.scene_s1(seed=5557)
+    model = pipeline.make_inference_model(cpu, dev, torch.float32, channels_last=True, graphs=True)
+    vox = pipeline.default_voxelizer(cfg.voxel_size, dev)
+    batch, out = _forward_group(model, [pipeline.SceneOnDevice(scene, dev)], vox)
+    off = batch["point_offsets"]
+    n_test = len(cfg.category_split["base_category"]) + len(cfg.category_split["novel_category"])
+    assert out["pred_logits"].shape[-1] == n_test + 1
+    for v in (1, 4):
+        ref = oracle_view(cpu, scene, v, (name, v))
+        rep = stage_report(out, v, slice(off[v], off[v + 1]), ref)
+        print(f"[parity {name} fp32 view {v}] " + " ".join(f"{k}={x:.3e}" for k, x in rep.items()))
+        assert rep["clip_queries_flipped"] <= 2
+        for k, bound in FP32.items():
+            assert rep[k] <= bound, f"{name}: {k} = {rep[k]:.3e} > {bound:.1e}"
+        assert rep["binary_agree"] > 0.999 and rep["ownership_agree"] > 0.995 and rep["point_label_agree"] > 0.9995

@@ -171,3 +171,29 @@ def test_unet_resblock_and_upsample_on_hip_convolutions(dev):
     assert pend is None and tuple(out.shape) == (2, 256, 32, 64)
     err = (out.float() - want).abs().max().item() / want.abs().max().item()
     assert err < 1e-2, err
+
+
+def test_conv3x3_groupnorm_relu_and_projection_bottleneck(dev):
+    """act = ReLU behind the GroupNorm (detectron2's GroupNorm BottleneckBlock, backbone/feature_extractor.py:20-60) and the projection
+    bottleneck that uses it: conv1 (1x1) -> [GN + ReLU fused into the 3x3 conv's staging] -> conv2 -> GN + ReLU -> conv3 (1x1) -> GN + skip -> ReLU"""
+    from xmask3d_amd import ops
+    from xmask3d_amd.image_branch import GNBottleneck
+
+    g = torch.Generator().manual_seed(21)
+    B, C, H, W, G = 2, 128, 16, 64, 32
+    x = _nhwc((torch.randn(B, C, H, W, generator=g) * 1.3).to(dev, torch.bfloat16))
+    w = (torch.randn(C, C, 3, 3, generator=g) / (3 * C ** 0.5)).to(dev, torch.bfloat16)
+    gamma, beta = (1 + 0.2 * torch.randn(C, generator=g)).to(dev), (0.3 * torch.randn(C, generator=g)).to(dev)
+    packed, tile = ops.conv3x3_pack_weight(w)
+    out = ops.conv3x3(x, packed, C, tile, gn=(ops.gn_stats_of(x, G), gamma, beta, 1e-5, G, "relu"), stats_groups=G)
+    ref = F.conv2d(F.relu(F.group_norm(x.float(), G, gamma, beta, 1e-5)).to(torch.bfloat16).float(), w.float(), None, padding=1)
+    err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-2, err
+
+    ref_m, fast_m = _module_pair(lambda: GNBottleneck(512, 128, 512), dev)
+    xb = torch.randn(2, 512, 32, 32, generator=g).to(dev, torch.bfloat16)
+    with torch.no_grad():
+        got = fast_m(_nhwc(xb))
+        want = ref_m(xb.float())
+    err = (got.float() - want).abs().max().item() / want.abs().max().item()
+    assert err < 3e-2, err

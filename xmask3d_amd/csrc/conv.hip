@@ -89,7 +89,8 @@ struct ConvGeom {
     static_assert(ROUNDS <= 8 && 36 % D == 0, "staging schedule / ring depth");
 };
 
-// MODE 0: x is the operand as it stands (plain convolution); MODE 2: operand = SiLU(GroupNorm(x)).
+// MODE 0: x is the operand as it stands (plain convolution); MODE 2: operand = SiLU(GroupNorm(x)); MODE 1: ReLU(GroupNorm(x)) (the
+// 3x3 convolution of detectron2's GroupNorm BottleneckBlock in the projection backbone, backbone/feature_extractor.py:20-60).
 // UPS: x has half the resolution, the operand is its nearest-neighbour 2x upsampling (ldm's Upsample -> conv).
 template <int CT, int MODE, bool UPS, int NW>
 __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
@@ -170,8 +171,13 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
         if constexpr (MODE != 0) {
             float y0 = fmaf(__uint_as_float(raw[i] << 16), sc[2 * i], sh[2 * i]);
             float y1 = fmaf(__uint_as_float(raw[i] & 0xFFFF0000u), sc[2 * i + 1], sh[2 * i + 1]);
-            y0 = y0 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-CV_LOG2E * y0));
-            y1 = y1 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-CV_LOG2E * y1));
+            if constexpr (MODE == 2) {  // SiLU
+                y0 = y0 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-CV_LOG2E * y0));
+                y1 = y1 * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-CV_LOG2E * y1));
+            } else {  // ReLU
+                y0 = fmaxf(y0, 0.f);
+                y1 = fmaxf(y1, 0.f);
+            }
             cv_bf16x2 pk;
             pk[0] = (__bf16)y0;
             pk[1] = (__bf16)y1;
@@ -422,8 +428,9 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
 }
 
 template <int CT, int NW>
-static int dispatch_conv(const ConvArgs& a, bool gn, bool upsample, hipStream_t s) {
-    if (gn) return launch_conv<CT, 2, false, NW>(a, s);
+static int dispatch_conv(const ConvArgs& a, int gn_act, bool upsample, hipStream_t s) {
+    if (gn_act == 1) return launch_conv<CT, 2, false, NW>(a, s);
+    if (gn_act == 2) return launch_conv<CT, 1, false, NW>(a, s);
     return upsample ? launch_conv<CT, 0, true, NW>(a, s) : launch_conv<CT, 0, false, NW>(a, s);
 }
 
@@ -482,7 +489,7 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
     if (gn) {
         XM3D_REQUIRE(gamma && beta && groups > 0 && cin % groups == 0, "conv3x3_nhwc: GroupNorm needs gamma, beta and groups dividing cin");
         XM3D_REQUIRE(ws, "conv3x3_nhwc: GroupNorm needs a workspace of xm3d_conv3x3_ws_bytes(B, cin) bytes");
-        XM3D_REQUIRE(act == 1, "conv3x3_nhwc: the fused GroupNorm is followed by SiLU (act 1)");
+        XM3D_REQUIRE(act == 1 || act == 2, "conv3x3_nhwc: the fused GroupNorm is followed by SiLU (act 1) or ReLU (act 2)");
         XM3D_REQUIRE(!upsample, "conv3x3_nhwc: upsample and GroupNorm cannot be combined");
     } else {
         XM3D_REQUIRE(act == 0, "conv3x3_nhwc: an activation needs the GroupNorm statistics");
@@ -517,6 +524,7 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
     a.tiles_x = W / CV_TW;
     a.tiles_y = H / TH;
     a.nct = cout / cout_tile;
-    if (cout_tile == 256) return waves == 8 ? dispatch_conv<256, 8>(a, gn, upsample != 0, s) : dispatch_conv<256, 4>(a, gn, upsample != 0, s);
-    return waves == 8 ? dispatch_conv<128, 8>(a, gn, upsample != 0, s) : dispatch_conv<128, 4>(a, gn, upsample != 0, s);
+    const int gn_act = gn ? act : 0;
+    if (cout_tile == 256) return waves == 8 ? dispatch_conv<256, 8>(a, gn_act, upsample != 0, s) : dispatch_conv<256, 4>(a, gn_act, upsample != 0, s);
+    return waves == 8 ? dispatch_conv<128, 8>(a, gn_act, upsample != 0, s) : dispatch_conv<128, 4>(a, gn_act, upsample != 0, s);
 }

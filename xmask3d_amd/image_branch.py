@@ -24,7 +24,8 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
-from .sd_model import ACT_NONE, ACT_RELU, AutoencoderKL, UNetModel, gn_act
+from . import ops
+from .sd_model import ACT_NONE, ACT_RELU, AutoencoderKL, UNetModel, _gn_f32, _packed, fused_conv_ok, gn_act
 
 SCALE_FACTOR = 0.18215
 # sqrt(alphas_cumprod[0]) and sqrt(1 - alphas_cumprod[0]) of the "ldm_linear" schedule
@@ -319,7 +320,19 @@ class GNBottleneck(nn.Module):
 
     def forward(self, x):
         # detectron2 BottleneckBlock: relu(conv3(...) + shortcut); add + ReLU ride in conv3's GroupNorm apply pass
-        return self.conv3(self.conv2(self.conv1(x)), residual=self.shortcut(x) if self.shortcut is not None else x, relu=True)
+        res = self.shortcut(x) if self.shortcut is not None else x
+        c1 = nn.Conv2d.forward(self.conv1, x)
+        if fused_conv_ok(c1, self.conv2):
+            # the 3x3 convolution on the HIP kernel: conv1's GroupNorm + ReLU are applied while its input tile is staged (one
+            # statistics pass over conv1's output instead of statistics + apply), and the moments for conv2's own GroupNorm come
+            # out of the epilogue (its apply pass, which conv3 - a library 1x1 convolution - needs materialised, skips the statistics)
+            packed, tile, _ = _packed(self.conv2)
+            gamma, beta = _gn_f32(self.conv1.norm)
+            n1 = self.conv1.norm
+            c2 = ops.conv3x3(c1, packed, self.conv2.out_channels, tile, gn=(ops.gn_stats_of(c1, n1.num_groups), gamma, beta, n1.eps, n1.num_groups, "relu"),
+                             stats_groups=self.conv2.norm.num_groups)
+            return self.conv3(gn_act(self.conv2.norm, c2, ACT_RELU), residual=res, relu=True)
+        return self.conv3(self.conv2(gn_act(self.conv1.norm, c1, ACT_RELU)), residual=res, relu=True)
 
 
 class FeatureExtractorBackbone(nn.Module):

@@ -511,7 +511,7 @@ def conv3x3_pack_weight(weight):
 def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_groups=None, upsample=False, in_shift=None, waves=0):
     """out = conv3x3(SiLU(GroupNorm(x))) + bias (+ residual), channels-last bf16 (B, C, H, W) in and out.
     packed, tile: conv3x3_pack_weight(weight).  gn: None (plain convolution) or (stats f64 (B*G*2), gamma f32 (cin), beta f32 (cin),
-    eps, G).  bias: None, (cout,) or (B, cout) f32.  residual: tensor like the output.  stats_groups: G of the GroupNorm that reads
+    eps, G[, "relu"]) - the activation behind the GroupNorm is SiLU unless "relu" is given.  bias: None, (cout,) or (B, cout) f32.  residual: tensor like the output.  stats_groups: G of the GroupNorm that reads
     the result next - its moments are accumulated in the epilogue and attached to the returned tensor (gn_stats_of picks them up).
     upsample: x is nearest-upsampled 2x first (plain convolution only).
     in_shift: (cin,) or (B, cin) f32 added to x in front of the GroupNorm (gn's moments must be those of x + in_shift).
@@ -532,11 +532,11 @@ def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_grou
     stats_in = gamma = beta = None
     eps, G, act = 0.0, 0, 0
     if gn is not None:
-        stats_in, gamma, beta, eps, G = gn
+        stats_in, gamma, beta, eps, G = gn[:5]
         if stats_in.dtype != torch.float64 or stats_in.numel() != B * G * 2 or gamma.dtype != torch.float32 or beta.dtype != torch.float32 \
                 or gamma.numel() != cin or beta.numel() != cin:
             raise TypeError("conv3x3: gn = (f64 moments (B*G*2), f32 gamma (cin), f32 beta (cin), eps, G)")
-        act = 1
+        act = 2 if (len(gn) > 5 and gn[5] == "relu") else 1
     sstride = 0
     if in_shift is not None:
         if gn is None or in_shift.dtype != torch.float32 or not in_shift.is_contiguous() or in_shift.numel() not in (cin, B * cin):
