@@ -296,6 +296,20 @@ int xm3d_attention_fwd(const void* q, const void* k, const void* v, void* out, i
                        int32_t D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
                        const int64_t* o_strides, const void* bias, int32_t bias_dtype, const int64_t* bias_strides,
                        float scale, void* stream);
+/* The same forward, also writing the per-row log-sum-exp the backward needs: lse2 (B, H, Nq) f32 = log2(sum_k exp2(score * log2 e)),
+ * i.e. in the log2 domain the kernel works in (1e30 for a row whose keys are all masked: its probabilities are zero). */
+int xm3d_attention_fwd_lse(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t D,
+                           const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
+                           const void* bias, int32_t bias_dtype, const int64_t* bias_strides, float scale, float* lse2, void* stream);
+/* Backward of the attention above (attention_bwd.hip): dq (B,Nq,H,D), dk / dv (B,Nk,H,D) bf16 CONTIGUOUS outputs, from q, k, v, the
+ * forward's out and lse2, and dout (the gradient w.r.t. out; element strides like the other operands).  The additive bias is a
+ * constant (no gradient).  delta_ws: B*H*Nq floats of scratch.  Replaces autograd through the reference's attention
+ * (loss.backward(), run/train.py:537, through ldm's CrossAttention: models/modeling/meta_arch/ldm.py:425-446,670-676).  Flash-style
+ * recomputation, two launches (dq + delta; dk, dv), no atomics: results are bit-reproducible. */
+int xm3d_attention_bwd(const void* q, const void* k, const void* v, const void* out, const void* dout, const float* lse2, int32_t B, int32_t H,
+                       int32_t Nq, int32_t Nk, int32_t D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                       const int64_t* o_strides, const int64_t* do_strides, const void* bias, int32_t bias_dtype, const int64_t* bias_strides,
+                       float scale, void* dq, void* dk, void* dv, float* delta_ws, void* stream);
 
 /* ---------------------------------------------------------------------------
  * Multi-scale deformable attention (replaces the pybind module

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
     const __bf16* __restrict__ Q, const __bf16* __restrict__ K, const __bf16* __restrict__ V, __bf16* __restrict__ O, int Nq,
     int Nk, int D, int64_t q_sb, int64_t q_sn, int64_t q_sh, int64_t k_sb, int64_t k_sn, int64_t k_sh, int64_t v_sb, int64_t v_sn,
     int64_t v_sh, int64_t o_sb, int64_t o_sn, int64_t o_sh, const void* __restrict__ bias, int64_t b_sb, int64_t b_sh, int64_t b_sq,
-    float scale_log2e) {
+    float scale_log2e, float* __restrict__ lse2) {
     constexpr int SQ = DQ / 16;   // k-steps of the score product
     constexpr int TV = DV / 32;   // 32-channel output tiles
     constexpr int KLD = DQ + 8;   // padded LDS rows (bf16): breaks the power-of-two stride of the fragment reads
@@ -254,6 +254,8 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
     }
     // ---- normalise and store O[q][32 tv + (r & 3) + 8 (r >> 2) + 4 h]: four runs of four consecutive channels per tile
     const int q = q0 + l31;
+    if (q < Nq && lse2 != nullptr && h == 0)  // log2-domain log-sum-exp of the row, for the backward kernels (attention_bwd.hip);
+        lse2[(int64_t(b) * gridDim.y + head) * Nq + q] = l_run > 0.f ? m_run + log2f(l_run) : 1e30f;  // a fully masked row: P = 0 there
     if (q < Nq) {
         const float inv = l_run > 0.f ? 1.f / l_run : 0.f;
         __bf16* Ob = O + b * o_sb + head * o_sh + int64_t(q) * o_sn;
@@ -276,10 +278,10 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
 
 using namespace xm3d;
 
-extern "C" int xm3d_attention_fwd(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t Nq, int32_t Nk,
-                                  int32_t D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
-                                  const int64_t* o_strides, const void* bias, int32_t bias_dtype, const int64_t* bias_strides,
-                                  float scale, void* stream) {
+static int attention_fwd_impl(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t Nq, int32_t Nk,
+                              int32_t D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                              const int64_t* o_strides, const void* bias, int32_t bias_dtype, const int64_t* bias_strides,
+                              float scale, float* lse2, void* stream) {
     XM3D_REQUIRE(B >= 0 && H >= 1 && Nq >= 0 && Nk >= 1 && D >= 8, "attention_fwd: bad sizes B=%d H=%d Nq=%d Nk=%d D=%d", B, H, Nq, Nk, D);
     XM3D_REQUIRE(D % 8 == 0 && D <= 160, "attention_fwd: head channels must be a multiple of 8 and <= 160 (got %d)", D);
     if (B == 0 || Nq == 0) return XM3D_OK;
@@ -300,7 +302,7 @@ extern "C" int xm3d_attention_fwd(const void* q, const void* k, const void* v, v
     hipLaunchKernelGGL((k_attn_fwd<DQ_, DV_, BI_>), grid, blk, 0, s, static_cast<const __bf16*>(q), static_cast<const __bf16*>(k),  \
                        static_cast<const __bf16*>(v), static_cast<__bf16*>(out), Nq, Nk, D, q_strides[0], q_strides[1], q_strides[2], \
                        k_strides[0], k_strides[1], k_strides[2], v_strides[0], v_strides[1], v_strides[2], o_strides[0], o_strides[1], \
-                       o_strides[2], bias, bs[0], bs[1], bs[2], sl2)
+                       o_strides[2], bias, bs[0], bs[1], bs[2], sl2, lse2)
 #define XM3D_ATT_D(DQ_, DV_)                       \
     do {                                           \
         if (bias_dtype == 0) XM3D_ATT(DQ_, DV_, 0); \
@@ -318,4 +320,21 @@ extern "C" int xm3d_attention_fwd(const void* q, const void* k, const void* v, v
 #undef XM3D_ATT
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
+}
+
+extern "C" int xm3d_attention_fwd(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t Nq, int32_t Nk,
+                                  int32_t D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                  const int64_t* o_strides, const void* bias, int32_t bias_dtype, const int64_t* bias_strides,
+                                  float scale, void* stream) {
+    return attention_fwd_impl(q, k, v, out, B, H, Nq, Nk, D, q_strides, k_strides, v_strides, o_strides, bias, bias_dtype, bias_strides, scale,
+                              nullptr, stream);
+}
+
+extern "C" int xm3d_attention_fwd_lse(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t Nq, int32_t Nk,
+                                      int32_t D, const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides,
+                                      const int64_t* o_strides, const void* bias, int32_t bias_dtype, const int64_t* bias_strides,
+                                      float scale, float* lse2, void* stream) {
+    XM3D_REQUIRE(lse2 != nullptr, "attention_fwd_lse: null lse2");
+    return attention_fwd_impl(q, k, v, out, B, H, Nq, Nk, D, q_strides, k_strides, v_strides, o_strides, bias, bias_dtype, bias_strides, scale,
+                              lse2, stream);
 }

@@ -725,6 +725,80 @@ def attention(q, k, v, bias=None, scale=None, out=None):
     return out
 
 
+def _att_ok(q, k, v, bias):
+    for t in (q, k, v):
+        if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 4 or t.stride(3) != 1 or t.data_ptr() % 16:
+            return False
+        if any(st % 8 for st in t.stride()[:3]):
+            return False
+    D = q.shape[3]
+    if D % 8 or D > 160 or k.shape[3] != D or v.shape[3] != D or k.shape[1] != v.shape[1] or k.shape[1] < 1:
+        return False
+    if bias is not None and (not bias.is_cuda or bias.dtype not in (torch.float32, torch.bfloat16) or bias.dim() != 4 or bias.stride(3) != 1
+                             or bias.requires_grad):
+        return False
+    return True
+
+
+def attention_train_supported(q, k, v, bias=None):
+    """True when the differentiable HIP attention (forward with log-sum-exp + xm3d_attention_bwd) takes these bf16 tensors: the
+    training path through the bf16 frozen UNet.  f32 operands keep torch's math backend (exact in f32)."""
+    return (not _ATTENTION_OFF and torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)
+            and _att_ok(q, k, v, bias))
+
+
+def _st3(t):
+    return (ctypes.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+
+def _bias_args(bias, B, H, Nq, Nk):
+    if bias is None:
+        return 0, None
+    if bias.shape[-2:] != (Nq, Nk) or bias.shape[0] not in (1, B) or bias.shape[1] not in (1, H):
+        raise RuntimeError(f"attention: bias shape {tuple(bias.shape)} does not broadcast to ({B},{H},{Nq},{Nk})")
+    return (1 if bias.dtype == torch.float32 else 2,
+            (ctypes.c_int64 * 3)(bias.stride(0) if bias.shape[0] > 1 else 0, bias.stride(1) if bias.shape[1] > 1 else 0, bias.stride(2)))
+
+
+class _AttentionFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, q, k, v, bias, scale):
+        B, Nq, H, D = q.shape
+        Nk = k.shape[1]
+        out = torch.empty((B, Nq, H, D), dtype=torch.bfloat16, device=q.device)
+        lse = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+        bdt, bst = _bias_args(bias, B, H, Nq, Nk)
+        check(lib().xm3d_attention_fwd_lse(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Nq, Nk, D, _st3(q), _st3(k), _st3(v), _st3(out), _ptr(bias),
+                                           bdt, bst, float(scale), _ptr(lse), _stream()), "xm3d_attention_fwd_lse")
+        ctx.save_for_backward(q, k, v, out, lse, bias)
+        ctx.scale = float(scale)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dout):
+        q, k, v, out, lse, bias = ctx.saved_tensors
+        B, Nq, H, D = q.shape
+        Nk = k.shape[1]
+        dout = dout.to(torch.bfloat16)
+        if dout.stride(3) != 1 or any(s % 8 for s in dout.stride()[:3]) or dout.data_ptr() % 16:
+            dout = dout.contiguous()
+        dq = torch.empty((B, Nq, H, D), dtype=torch.bfloat16, device=q.device)
+        dk = torch.empty((B, Nk, H, D), dtype=torch.bfloat16, device=q.device)
+        dv = torch.empty((B, Nk, H, D), dtype=torch.bfloat16, device=q.device)
+        ws = torch.empty((B, H, Nq), dtype=torch.float32, device=q.device)
+        bdt, bst = _bias_args(bias, B, H, Nq, Nk)
+        check(lib().xm3d_attention_bwd(_ptr(q), _ptr(k), _ptr(v), _ptr(out), _ptr(dout), _ptr(lse), B, H, Nq, Nk, D, _st3(q), _st3(k), _st3(v),
+                                       _st3(out), _st3(dout), _ptr(bias), bdt, bst, ctx.scale, _ptr(dq), _ptr(dk), _ptr(dv), _ptr(ws), _stream()),
+              "xm3d_attention_bwd")
+        return dq, dk, dv, None, None
+
+
+def attention_train(q, k, v, bias=None, scale=None):
+    """differentiable softmax(q k^T * scale + bias) v on the HIP kernels (bf16 (B,N,H,D) views, see attention()); the bias is a constant"""
+    return _AttentionFn.apply(q, k, v, bias, q.shape[3] ** -0.5 if scale is None else scale)
+
+
 # ---------------------------------------------------------------- deformable attention
 def _msda_dtype(value):
     if value.dtype not in (torch.float32, torch.float64):

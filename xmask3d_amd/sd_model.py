@@ -411,6 +411,8 @@ class CrossAttention(nn.Module):
         v = self.to_v(context).view(b, context.shape[1], h, -1)
         if ops.attention_supported(q, k, v):  # bf16 inference: HIP flash attention on the (B, N, H*D) projections in place
             return self.to_out(ops.attention(q, k, v).view(b, n, -1))
+        if ops.attention_train_supported(q, k, v):  # bf16 under autograd (training through the frozen UNet): HIP forward + backward
+            return self.to_out(ops.attention_train(q, k, v).reshape(b, n, -1))
         o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).reshape(b, n, -1)
         return self.to_out(o)
 
