@@ -145,6 +145,61 @@ def spconv_roofline(dev):
             "f32_input_split_on_the_fly_us": ms_f32in * 1e3, "exact_f32_kernel_us": ms3 * 1e3, "exact_f32_kernel_frac": flop / (ms3 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF}
 
 
+def sparse_network_roofline(dev, model):
+    """`roofline_sparse_network`: both sparse U-Nets (MinkUNet34C + MinkUNet18A, heads included) on the FULL S1 cloud (S1-full, SURVEY
+    8d: 106 950 voxels): algorithmic 379.3 GFLOP (convolutions, measured pair counts) + 42.6 GFLOP (heads) per forward / measured
+    time, against the f32 matrix peak the split-operand kernels are priced on.  HIP events around whole forwards (rulebooks included:
+    they are rebuilt every forward, as in training)."""
+    from xmask3d_amd import me_compat as ME, ops, synthetic
+
+    sc = synthetic.scene_s1()
+    grid, inds, inv = ops.voxelize(torch.from_numpy(sc.points).to(dev), np.diag([50.0, 50.0, 50.0, 1.0]))
+    coords = torch.cat([torch.zeros(grid.shape[0], 1, dtype=torch.int32, device=dev), grid], 1).contiguous()
+    feats = (torch.from_numpy(sc.colors).to(dev)[inds] / 127.5 - 1).float().contiguous()
+
+    def once():
+        with torch.no_grad():
+            sp = ME.SparseTensor(feats, coords)
+            model.pc_decoder(sp)
+            model.pc_binary_head(sp)
+
+    ms = event_ms(once, 5)
+    gflop = 379.3 + 42.6
+    tf = gflop / ms  # GFLOP / ms = TFLOP/s
+    return {"kernel": "MinkUNet34C + MinkUNet18A on S1-full (k_spconv_split / k_spconv_tiles + rulebook kernels)", "bound": "mfma", "achieved": tf,
+            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF, "ms_per_forward": ms, "voxels": int(coords.shape[0]),
+            "algorithmic_gflop": gflop, "note": "network level: coordinate / rulebook kernels, BatchNorm folding and the two Linear heads inside the time"}
+
+
+def spconv_window_roofline(dev, sd, voxelizer, n_views):
+    """`roofline_spconv_window`: the sparse-conv instantiation with the largest share of the timed window, k_spconv_split<4,1,64,8,3,2,true>
+    = the 64 -> 64 channel k = 3 layers at tensor stride 2 (MinkUNet block 2), on the coordinates of the bench forward itself (`n_views`
+    views in one batch), pre-split input and split output as inside the network; pair count read live from the kernel map."""
+    from xmask3d_amd import ops, pipeline
+
+    mats = [np.diag([50.0, 50.0, 50.0, 1.0])] * n_views
+    batch = pipeline.build_scene_batch(sd, [i % len(sd.views) for i in range(n_views)], voxelizer, mats)
+    cm = ops.CoordinateManager(batch["coords"] if "coords" in batch else batch["sinput"].C)
+    nbr, tiles, order = cm.kernel_map(2, 2, 3), cm.tiles(2, 2, 3), cm.order(2)
+    n = cm.num(2)
+    pairs = int((nbr >= 0).sum().item())
+    cin = cout = 64
+    g = torch.Generator(device="cpu").manual_seed(2)
+    feats = torch.randn(n, cin, generator=g).to(dev)
+    W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev)
+    p4 = ops.pack_weight_split(W)
+    fs = torch.stack([feats.bfloat16(), (feats - feats.bfloat16().float()).bfloat16()]).contiguous()
+    ms = event_ms(lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=p4, tiles=tiles, relu=True, algo=ops.ALGO_SPLIT, feats_split=fs,
+                                         want_split=True), 20)
+    flop = 2.0 * pairs * cin * cout
+    tf = flop / (ms * 1e-3) / 1e12
+    return {"kernel": "xm3d::k_spconv_split<4,1,64,8,3,2,true>", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": tf / FP32_MFMA_PEAK_TF, "traffic": pmc_traffic("k_spconv_split<4,1,64,8,3,2,true>"), "avg_launch_us": ms * 1e3, "pairs": pairs,
+            "voxels": n, "cin": cin, "cout": cout, "views": n_views,
+            "algorithmic_bytes_gather_scatter": pairs * (cin + cout) * 4 + pairs * 8 + 27 * cin * cout * 4,
+            "algorithmic_bytes_compulsory": (2 * n * cin + 27 * cin * cout) * 4 + 8 * pairs}
+
+
 def kernel_rooflines(dev):
     """`roofline_kernels`: the other hand-written kernels that show up in the timed window, each measured live (HIP events)
     on the shape it runs at in the bench forward (20 views) against the roof that bounds it."""
@@ -548,7 +603,8 @@ def main():
                    "dead_compute": "as reference" if args.faithful_dead_compute else "pruned (SURVEY F7)",
                    "layout": "NCHW" if args.nchw else "channels-last (NHWC) frozen nets",
                    "schedule": "eager launches" if args.no_graph else "3 HIP graphs per forward (2 slots), next forward's front software-pipelined on side streams"},
-        "roofline": roofline, "roofline_spconv": roofline_spconv, "roofline_dense_stage": roofline_stage, "roofline_kernels": kernel_rooflines(dev),
+        "roofline": roofline, "roofline_spconv": roofline_spconv, "roofline_spconv_window": spconv_window_roofline(dev, sd, voxelizer, vb),
+        "roofline_sparse_network": sparse_network_roofline(dev, model), "roofline_dense_stage": roofline_stage, "roofline_kernels": kernel_rooflines(dev),
         "cpu_baseline": cpu_baseline, "latency_ms_single_scene": latency_ms, "fp32": fp32, "train": None,
     }
     finish(None)

@@ -296,9 +296,12 @@ def postprocess_scene(cfg, outputs, batch, with_ablations=True):
     n_seg = len(offsets) - 1
     fill = nearest_valid_fill_segmented(batch["ori_coords"][:, 1:], ~empty, vid, n_seg,
                                         max(offsets[i + 1] - offsets[i] for i in range(n_seg)))
-    f2d = f2d[fill]  # points without a 2D feature take the nearest covered point's of the same view (infer.py:523-553)
-    pred2d = _gate(scale * (F.normalize(f2d, dim=-1) @ text.t()), binary_pred, base, novel).argmax(1)
-    pred3d = _gate(scale * (F.normalize(outputs["pure3d_cat"], dim=-1) @ text.t()), binary_pred, base, novel).argmax(1)
+    # The 2D-only and 3D-only labels are arg-maxima of scale * cos(feature, text) over the gated classes: the positive per-point
+    # factor scale / |feature| does not move an arg-max, so the (Np, 768) features are neither normalised (a read + write pass
+    # each) nor gathered - the (Np, C) products are, after the GEMM.  Points without a 2D feature take the nearest covered
+    # point's of the same view (infer.py:523-553): its row of the product.
+    pred2d = _gate((f2d @ text.t())[fill], binary_pred, base, novel).argmax(1)
+    pred3d = _gate(outputs["pure3d_cat"] @ text.t(), binary_pred, base, novel).argmax(1)
     return pred, pred2d, pred3d
 
 
