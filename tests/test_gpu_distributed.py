@@ -77,5 +77,7 @@ def test_sharded_inference_equals_single_process(dev, tmp_path):
         for k in one[name]:
             assert r0[name][k] == r1[name][k]                      # every rank holds the all-reduced result
             # not bit-equal: GroupNorm moments are accumulated with floating-point atomics, whose order differs from run to run,
-            # and a last-bit difference flips the arg-max of a handful of the 480 k points (measured 4e-6 on the score)
-            assert abs(r0[name][k] - one[name][k]) < 1e-4, (name, k, r0[name][k], one[name][k])
+            # and a last-bit difference flips the arg-max of a handful of the 480 k points (measured 4e-6 on hIoU, 1.1e-4 on the
+            # 4-class mIoU_novel).  A sharding error - a scene missing or counted twice - moves every score by tens of percent of
+            # its value (each scene carries a quarter of the counts)
+            assert abs(r0[name][k] - one[name][k]) < 1e-3, (name, k, r0[name][k], one[name][k])
