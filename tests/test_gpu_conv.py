@@ -197,3 +197,35 @@ def test_conv3x3_groupnorm_relu_and_projection_bottleneck(dev):
         want = ref_m(xb.float())
     err = (got.float() - want).abs().max().item() / want.abs().max().item()
     assert err < 3e-2, err
+
+
+# every (cin, cout, H, W) the bench forward sends to the kernel (tools: /tmp shape trace of sd_model on meta tensors),
+# at the TRUE spatial size, one view: VAE encoder / decoder ResnetBlocks, UNet ResBlocks at 64^2 / 32^2, projection bottleneck
+PATH_SHAPES = [(128, 128, 512, 512), (128, 256, 256, 256), (256, 256, 256, 256), (256, 512, 128, 128), (512, 512, 128, 128),
+               (512, 512, 64, 64), (640, 640, 64, 64), (320, 640, 32, 32), (640, 640, 32, 32), (1280, 1280, 32, 32),
+               (1920, 640, 32, 32), (1280, 640, 32, 32), (960, 640, 32, 32), (128, 128, 128, 128)]
+
+
+@pytest.mark.parametrize("cin,cout,H,W", PATH_SHAPES)
+def test_conv3x3_every_shape_of_the_path_matches_torch_fp32(dev, cin, cout, H, W):
+    from xmask3d_amd import ops
+
+    g = torch.Generator().manual_seed(cin + 3 * cout + H)
+    G = 32
+    x = _nhwc((torch.randn(1, cin, H, W, generator=g) * 1.5 + 0.2 * torch.randn(1, cin, 1, 1, generator=g)).to(dev, torch.bfloat16))
+    w = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev, torch.bfloat16)
+    gamma, beta = (1 + 0.2 * torch.randn(cin, generator=g)).to(dev), (0.2 * torch.randn(cin, generator=g)).to(dev)
+    bias = (0.3 * torch.randn(cout, generator=g)).to(dev)
+    residual = _nhwc(torch.randn(1, cout, H, W, generator=g).to(dev, torch.bfloat16))
+    packed, tile = ops.conv3x3_pack_weight(w)
+    gs = 32 if (cout // 32) % 4 == 0 else None
+    out = ops.conv3x3(x, packed, cout, tile, bias=bias, gn=(ops.gn_stats_of(x, G), gamma, beta, 1e-5, G), residual=residual, stats_groups=gs)
+    xn = F.silu(F.group_norm(x.float(), G, gamma, beta, 1e-5)).to(torch.bfloat16).float()
+    ref = F.conv2d(xn, w.float(), bias, padding=1) + residual.float()
+    err = (out.float() - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 1e-2, err
+    if gs:
+        st = ops.gn_stats_of(out, gs).view(1, gs, 2)
+        o = out.float().view(1, gs, cout // gs, H * W)
+        want = torch.stack([o.sum((2, 3)), (o * o).sum((2, 3))], -1).double()
+        assert ((st - want).abs() / (want.abs() + 1.0)).max().item() < 1e-4
