@@ -76,7 +76,7 @@ def pmc_traffic(kernel_key):
 
 
 def conv_roofline(dev):
-    """Roofline of the time-dominant hand-written kernel, k_conv3x3<256,2,false> (csrc/conv.hip), on the shape with the largest
+    """Roofline of the time-dominant hand-written kernel, k_conv3x3<256,2,false,NW> (csrc/conv.hip), on the shape with the largest
     share of the forward: the 512 -> 512 channel ResnetBlock convolution of the SD VAE at 128 x 128, 20 views, with everything
     the bench forward fuses into it (GroupNorm affine + SiLU on the staged input, bias, residual, output moments).
     Algorithmic FLOP = 2 * B*H*W * 9*Cin * Cout per launch; bytes = input + residual + output (bf16) + weights."""
@@ -97,8 +97,10 @@ def conv_roofline(dev):
     flop = 2.0 * B * H * W * 9 * C * C
     nbytes = B * H * W * (C + 2 * C) * 2 + 9 * C * C * 2
     tf = flop / (ms * 1e-3) / 1e12
-    return {"kernel": "xm3d::k_conv3x3<256,2,false>", "bound": "mfma", "achieved": tf, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": tf / BF16_MFMA_PEAK_TF, "traffic": pmc_traffic("k_conv3x3<256,2,false>"), "algorithmic_bytes": nbytes,
+    waves = ops.lib().xm3d_conv3x3_default_waves(H, W, C, C)  # the geometry the forward uses for this layer
+    kname = f"k_conv3x3<256,2,false,{waves}>"
+    return {"kernel": "xm3d::" + kname, "bound": "mfma", "achieved": tf, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
+            "frac": tf / BF16_MFMA_PEAK_TF, "traffic": pmc_traffic(kname), "algorithmic_bytes": nbytes,
             "avg_launch_us": ms * 1e3, "shape": f"{B} x {H}x{W} x {C}->{C}, GroupNorm(32)+SiLU in, bias+residual+moments out",
             "plain_conv_us": ms_plain * 1e3, "plain_conv_frac": flop / (ms_plain * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF,
             "library_conv_alone_us": ms_lib * 1e3, "library_conv_alone_frac": flop / (ms_lib * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF}
@@ -289,6 +291,10 @@ def train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log, train_dt
     for i in range(2):
         it(i)
     torch.cuda.synchronize()
+    import gc
+
+    gc.collect()
+    gc.freeze()  # the step is host-bound: a generation-2 pass of python's cyclic GC over the model objects inside 4-8 timed steps is +30 %
     if world > 1:
         dist.barrier()
     t0 = time.perf_counter()
@@ -323,7 +329,7 @@ def main():
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find through the shipped find-db)")
     ap.add_argument("--scenes-per-forward", type=int, default=4,
                     help="scenes whose views share one forward (views are independent until the vote); 1 = one scene per forward")
-    ap.add_argument("--train-steps", type=int, default=4,
+    ap.add_argument("--train-steps", type=int, default=8,
                     help="training iterations timed after the inference steps (1 view per GPU, DDP when --gpus > 1), reported under "
                          "\"train\" (fp32 as the reference trains, plus a bf16-frozen-nets run); 0 = skip")
     ap.add_argument("--train-deadline", type=int, default=300,
@@ -362,7 +368,11 @@ def main():
             dist.init_process_group(backend=backend)
 
     if args.roofline_only:
-        print(json.dumps({"roofline": conv_roofline(dev), "roofline_spconv": spconv_roofline(dev)}))
+        from xmask3d_amd import pipeline as _pl, synthetic as _syn
+
+        _sd = _pl.SceneOnDevice(_syn.scene_s1(seed=5557), dev)
+        print(json.dumps({"roofline": conv_roofline(dev), "roofline_spconv": spconv_roofline(dev),
+                          "roofline_spconv_window": spconv_window_roofline(dev, _sd, _pl.default_voxelizer(0.02, dev), 20)}))
         return
 
     import __graft_entry__
