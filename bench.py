@@ -98,10 +98,14 @@ def conv_roofline(dev):
     nbytes = B * H * W * (C + 2 * C) * 2 + 9 * C * C * 2
     tf = flop / (ms * 1e-3) / 1e12
     waves = ops.lib().xm3d_conv3x3_default_waves(H, W, C, C)  # the geometry the forward uses for this layer
+    other = 4 if waves == 8 else 8  # the other geometry, timed beside it (and so present in the PMC passes of tools/roofline_profile.sh)
+    ms_other = event_ms(lambda: ops.conv3x3(x, packed, C, tile, bias=bias, gn=(stats, gamma, beta, 1e-6, G), residual=res, stats_groups=G,
+                                            waves=other), 5)
     kname = f"k_conv3x3<256,2,false,{waves}>"
     return {"kernel": "xm3d::" + kname, "bound": "mfma", "achieved": tf, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s",
             "frac": tf / BF16_MFMA_PEAK_TF, "traffic": pmc_traffic(kname), "algorithmic_bytes": nbytes,
             "avg_launch_us": ms * 1e3, "shape": f"{B} x {H}x{W} x {C}->{C}, GroupNorm(32)+SiLU in, bias+residual+moments out",
+            f"geometry_{other}_waves_us": ms_other * 1e3, f"geometry_{other}_waves_traffic": pmc_traffic(f"k_conv3x3<256,2,false,{other}>"),
             "plain_conv_us": ms_plain * 1e3, "plain_conv_frac": flop / (ms_plain * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF,
             "library_conv_alone_us": ms_lib * 1e3, "library_conv_alone_frac": flop / (ms_lib * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF}
 
@@ -463,10 +467,20 @@ def main():
         capture(model, 1, 1)
         log(f"HIP graphs captured for {G} scene(s) per forward")
     log("model on device; warmup")
-    for i in range(args.warmup):
-        run(model, 1)
+    # warm-up on the SCHEDULE the timed region runs: whole groups of G scenes per forward, consecutive groups pipelined.  (Until
+    # round 3 the W warm-up steps ran one scene per forward, so the first G-scene forwards - allocator growth for the 4-scene
+    # sparse batch, lazily loaded library kernels for its shapes - fell inside the timed region: one run in eight lost ~120 ms
+    # there, profiles/r03_bench_geometry_ab.log group 0.)  W steps rounded up to whole groups, at least two groups.
+    n_warm = max(2, -(-args.warmup // G)) * G if graphed else args.warmup
+    if graphed:
+        run(model, n_warm)
         torch.cuda.synchronize()
-        log(f"warmup step {i} done")
+        log(f"warmup: {n_warm} scenes in groups of {G} done")
+    else:
+        for i in range(args.warmup):
+            run(model, 1)
+            torch.cuda.synchronize()
+            log(f"warmup step {i} done")
     torch.cuda.synchronize()
     # the model, its HIP graphs and the scene tables are millions of long-lived python objects: move them to the permanent
     # generation so that a cyclic-GC pass inside the timed loop stays cheap (an unfrozen gen-2 pass stalls the host ~50 ms,

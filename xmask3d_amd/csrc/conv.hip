@@ -308,60 +308,74 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
             for (int n = 0; n < NT; ++n) t += acc[m][n][0];
         if (t == 123.456f) a.out[0] = (__bf16)t;
     } else {
+        // the packed weights put channel 16 h + i of a row block's 32 on MFMA row (i & 3) + 8 (i >> 2) + 4 h, i.e. in accumulator
+        // register i of lane (pixel, h): a lane owns 16 CONSECUTIVE channels of one pixel = two 16-byte accesses.  Pixel row outer,
+        // row block inner: the wave's MB x 64 bytes of a pixel (a whole 128-byte line for MB = 2) are stored back to back - with the
+        // row block outer the two halves of a line left L2 separately (WRITE_SIZE 1.22 x the output, profiles/r03_roofline_pmc.txt)
+        float gs[MB][4], gq[MB][4];
+        float4 bq[MB][4];
 #pragma unroll
-        for (int m = 0; m < MB; ++m) {
-            // the packed weights put channel 16 h + i of a row block's 32 on MFMA row (i & 3) + 8 (i >> 2) + 4 h, i.e. in accumulator
-            // register i of lane (pixel, h): a lane owns 16 CONSECUTIVE channels of one pixel = two 16-byte accesses
-            const int chl = (wb0 + m) * 32 + 16 * h;  // + i : channel inside the tile
-            float gs[4] = {0.f, 0.f, 0.f, 0.f}, gq[4] = {0.f, 0.f, 0.f, 0.f};
-            float4 bq[4];
+        for (int m = 0; m < MB; ++m)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) bq[q] = bias ? *reinterpret_cast<const float4*>(bias + chl + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int q = 0; q < 4; ++q) {
+                gs[m][q] = gq[m][q] = 0.f;
+                bq[m][q] = bias ? *reinterpret_cast<const float4*>(bias + (wb0 + m) * 32 + 16 * h + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+            }
 #pragma unroll
-            for (int n = 0; n < NT; ++n) {
-                const int y = ty * TH + nbase + n, px = tx * CV_TW + l31;
-                const int64_t o = ((int64_t(b) * H + y) * W + px) * a.cout + ct * CT + chl;
-                uint4 rr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+        for (int n = 0; n < NT; ++n) {
+            const int y = ty * TH + nbase + n, px = tx * CV_TW + l31;
+            const int64_t opix = ((int64_t(b) * H + y) * W + px) * a.cout + ct * CT;
+            uint4 rr[MB][2];
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                rr[m][0] = rr[m][1] = make_uint4(0, 0, 0, 0);
                 if (a.residual) {
-                    rr[0] = *reinterpret_cast<const uint4*>(a.residual + o);
-                    rr[1] = *reinterpret_cast<const uint4*>(a.residual + o + 8);
+                    const int64_t o = opix + (wb0 + m) * 32 + 16 * h;
+                    rr[m][0] = *reinterpret_cast<const uint4*>(a.residual + o);
+                    rr[m][1] = *reinterpret_cast<const uint4*>(a.residual + o + 8);
                 }
-                const unsigned rw[8] = {rr[0].x, rr[0].y, rr[0].z, rr[0].w, rr[1].x, rr[1].y, rr[1].z, rr[1].w};
+            }
+#pragma unroll
+            for (int m = 0; m < MB; ++m) {
+                const int64_t o = opix + (wb0 + m) * 32 + 16 * h;
+                const unsigned rw[8] = {rr[m][0].x, rr[m][0].y, rr[m][0].z, rr[m][0].w, rr[m][1].x, rr[m][1].y, rr[m][1].z, rr[m][1].w};
                 cv_bf16x8 pk[2];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    const float v[4] = {acc[m][n][4 * q] + bq[q].x + __uint_as_float(rw[2 * q] << 16),
-                                        acc[m][n][4 * q + 1] + bq[q].y + __uint_as_float(rw[2 * q] & 0xFFFF0000u),
-                                        acc[m][n][4 * q + 2] + bq[q].z + __uint_as_float(rw[2 * q + 1] << 16),
-                                        acc[m][n][4 * q + 3] + bq[q].w + __uint_as_float(rw[2 * q + 1] & 0xFFFF0000u)};
+                    const float v[4] = {acc[m][n][4 * q] + bq[m][q].x + __uint_as_float(rw[2 * q] << 16),
+                                        acc[m][n][4 * q + 1] + bq[m][q].y + __uint_as_float(rw[2 * q] & 0xFFFF0000u),
+                                        acc[m][n][4 * q + 2] + bq[m][q].z + __uint_as_float(rw[2 * q + 1] << 16),
+                                        acc[m][n][4 * q + 3] + bq[m][q].w + __uint_as_float(rw[2 * q + 1] & 0xFFFF0000u)};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
                         const __bf16 r = (__bf16)v[j];
                         pk[q >> 1][(q & 1) * 4 + j] = r;
                         const float vr = (float)r;
-                        gs[q] += vr;
-                        gq[q] = fmaf(vr, vr, gq[q]);
+                        gs[m][q] += vr;
+                        gq[m][q] = fmaf(vr, vr, gq[m][q]);
                     }
                 }
                 *reinterpret_cast<cv_bf16x8*>(a.out + o) = pk[0];
                 *reinterpret_cast<cv_bf16x8*>(a.out + o + 8) = pk[1];
             }
-            if (want_stats) {
+        }
+        if (want_stats) {
+#pragma unroll
+            for (int m = 0; m < MB; ++m)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float s = gs[q], ss = gq[q];
+                    float s = gs[m][q], ss = gq[m][q];
 #pragma unroll
                     for (int off = 16; off > 0; off >>= 1) {
                         s += __shfl_xor(s, off);
                         ss += __shfl_xor(ss, off);
                     }
                     if (l31 == 0) {
-                        const int gl = (ct * CT + chl + 4 * q) / cg_out - g_first;
+                        const int gl = (ct * CT + (wb0 + m) * 32 + 16 * h + 4 * q) / cg_out - g_first;
                         atomicAdd(&sred[2 * gl], s);
                         atomicAdd(&sred[2 * gl + 1], ss);
                     }
                 }
-            }
         }
     }
     if (want_stats) {
@@ -457,9 +471,15 @@ extern "C" int xm3d_conv3x3_default_waves(int H, int W, int cin, int cout) {
     (void)W;
     (void)cout;
     if (H % 8 != 0) return 4;
-    // VAE shapes (cin 128 .. 512 at 64^2 .. 512^2): 2 - 14 % faster with two 4-wave workgroups per CU; the UNet's cin >= 640 at 32^2
-    // (few tiles per CU, long K loop): 3 - 4 % faster with one 8-wave workgroup
-    return cin <= 512 ? 4 : 8;
+    // Alone, two 4-wave workgroups per CU are 2 - 14 % faster on the VAE's layers (prologue and epilogue overlap the other
+    // workgroup's MFMAs) and one 8-wave workgroup 3 - 4 % on the UNet's cin >= 640 at 32^2 (profiles/r03_conv_bench_v4.log).  Inside
+    // the forward, where the UNet, the VAE decoder and the sparse 3D branch share the chip on three streams, the 8-wave geometry
+    // wins on every layer it was tried on: it moves 1.25 x fewer bytes (halo 1.33 x instead of 1.59 x; 1.40 vs 1.76 GB on
+    // 512 ch @ 128^2, profiles/roofline_pmc.json).  End to end, scenes/s: 8-wave everywhere 36.4 / 36.0, 4-wave for cin <= 512
+    // below 128^2 35.6, 4-wave for cin <= 128 35.4, 4-wave everywhere 35.4 (profiles/r03_bench_geometry_ab.log).  The 4-wave
+    // geometry stays for heights that are a multiple of 4 only, and as a caller's explicit choice.
+    (void)cin;
+    return 8;
 }
 
 extern "C" int64_t xm3d_conv3x3_ws_bytes(int64_t B, int32_t cin) { return B > 0 && cin > 0 ? B * int64_t(cin) * 2 * int64_t(sizeof(float)) : 0; }

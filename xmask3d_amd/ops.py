@@ -508,6 +508,9 @@ def conv3x3_pack_weight(weight):
     return packed, tile
 
 
+_CONV_WAVES = int(_os.environ.get("XM3D_CONV_WAVES", "0"))  # A/B switch for bench runs: force one workgroup geometry (0 = per-layer choice)
+
+
 def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_groups=None, upsample=False, in_shift=None, waves=0):
     """out = conv3x3(SiLU(GroupNorm(x))) + bias (+ residual), channels-last bf16 (B, C, H, W) in and out.
     packed, tile: conv3x3_pack_weight(weight).  gn: None (plain convolution) or (stats f64 (B*G*2), gamma f32 (cin), beta f32 (cin),
@@ -549,7 +552,7 @@ def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_grou
         ws = torch.empty(B * cin * 2, dtype=torch.float32, device=x.device)
     check(lib().xm3d_conv3x3_nhwc(_ptr(x), B, H, W, cin, _ptr(packed), cout, tile, _ptr(stats_in), _ptr(gamma), _ptr(beta), _ptr(in_shift), sstride,
                                   float(eps), int(G), act, _ptr(bias), bstride, _ptr(residual), _ptr(out), _ptr(stats_out), int(stats_groups or 0), int(bool(upsample)),
-                                  int(waves), _ptr(ws), _stream()), "xm3d_conv3x3_nhwc")
+                                  int(waves) or _CONV_WAVES, _ptr(ws), _stream()), "xm3d_conv3x3_nhwc")
     if stats_out is not None:
         out._xm3d_gn_stats = (stats_out, int(stats_groups), out.data_ptr())
     return out
