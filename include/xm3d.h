@@ -243,6 +243,28 @@ int xm3d_conv3x3_nhwc(const void* x, int64_t B, int32_t H, int32_t W, int32_t ci
 /* waves of a workgroup the call above uses when waves = 0: 8 (8 x 32 pixel tile, one workgroup per CU) or 4 (4 x 32 pixel tile, two
  * workgroups per CU, whose memory-bound prologue / epilogue overlap each other's matrix work) */
 int xm3d_conv3x3_default_waves(int32_t H, int32_t W, int32_t cin, int32_t cout);
+
+/* ---- linear layer / 1x1 convolution with fused epilogue (gemm.hip): the dense projections of the Stable-Diffusion UNet's
+ * SpatialTransformer (to_q / to_k / to_v / to_out, GEGLU feed-forward, 1x1 proj_in / proj_out: models/modeling/meta_arch/ldm.py:425-446
+ * -> ldm.modules.attention.{CrossAttention, FeedForward, SpatialTransformer}.forward -> torch.nn.Linear / Conv2d(1x1), cuBLAS /
+ * hipBLASLt there), the 1x1 q / k / v / proj_out of the VAE AttnBlock (:386-414, :448-490) and the c_fc / c_proj / in_proj / out_proj
+ * of the mask-CLIP ViT (models/modeling/meta_arch/clip.py:239-270 -> open_clip ResidualAttentionBlock).
+ *   out = act( x @ W^T + bias ) (+ residual)           act 0 none, 1 GELU (erf), 2 QuickGELU
+ *   out = (x @ Wv^T + bv) * GELU(x @ Wg^T + bg)        act 3 GEGLU: W = [Wv; Wg] (N = 2 N_out rows), out (M, N / 2)
+ * bf16 rows in / f32 accumulate / bf16 rows out, one launch.
+ *   xm3d_gemm_col_tile(N)        -> column tile for N rows of W (256 or 128)
+ *   xm3d_gemm_packed_elems       -> bf16 elements of the packed image (N padded to whole column tiles)
+ *   xm3d_gemm_pack_weight        : W (N, K) row-major, f32 (w_is_f32 = 1) or bf16 -> packed; `act` must be the epilogue the image will
+ *                                  be used with (GEGLU interleaves value and gate rows)
+ *   xm3d_gemm_bf16               : x (M, K) bf16 with row stride ldx; out / residual (M, N_out) with row strides ldo / ldr (elements);
+ *                                  bias (N) f32 or NULL; residual may be NULL.
+ *   Constraints: K % 64 == 0, N % 32 == 0, row strides multiples of 8 elements, 16-byte aligned tensors; any M > 0.
+ *   Launched on `stream`, no host synchronisation. */
+int xm3d_gemm_col_tile(int32_t n_rows);
+int64_t xm3d_gemm_packed_elems(int32_t n_rows, int32_t K, int32_t col_tile);
+int xm3d_gemm_pack_weight(const void* w, int32_t w_is_f32, int32_t N, int32_t K, int32_t act, int32_t col_tile, void* packed, void* stream);
+int xm3d_gemm_bf16(const void* x, int64_t M, int32_t K, int64_t ldx, const void* wpacked, int32_t N, int32_t col_tile, const float* bias, int32_t act,
+                   const void* residual, int64_t ldr, void* out, int64_t ldo, void* stream);
 /* GroupNorm moments alone, in the layout the calls above take: stats (B*G*2) f64 <- (sum, sum of squares) of x (+ shift) per
  * (sample, group); x (B, H*W, C) channels-last, dtype 0 = f32 / 1 = bf16; stats is zeroed here. */
 int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,

@@ -1,0 +1,376 @@
+// Linear layer / 1x1 convolution over bf16 token rows on the gfx950 matrix cores, with what follows it folded into the epilogue:
+//
+//     out = act( x @ W^T + bias ) (+ residual)            x (M, K) bf16 rows, W (N, K), out (M, N) bf16      act: none | GELU | QuickGELU
+//     out = (x @ Wv^T + bv) * GELU(x @ Wg^T + bg)          GEGLU: W = [Wv; Wg] (2 N_out, K), out (M, N_out)
+//
+// These are the dense projections around the attentions of the 3D-conditioned Stable-Diffusion UNet - to_q / to_k / to_v / to_out,
+// the GEGLU feed-forward and the 1x1 proj_in / proj_out of ldm's SpatialTransformer, reached from
+// /root/reference/models/modeling/meta_arch/ldm.py:425-446 - the 1x1 q / k / v / proj_out of the VAE's AttnBlock (:386-414,
+// :448-490) and the c_fc / c_proj / in_proj / out_proj of the mask-CLIP ViT-L (/root/reference/models/modeling/meta_arch/clip.py:
+// 239-270): north_star's "MFMA on the dense QKV / ResBlock / CLIP GEMMs".  The ResBlock 3x3 convolutions are conv.hip; this file
+// is the same machine with ONE filter tap and a flat token list instead of an image tile.
+//
+// Decomposition (one workgroup = 8 waves = 256 token rows x CT output columns, CT = 256 or 128):
+//   * K loop = chunks of 64 input channels x 4 MFMA k-steps of 16.
+//   * TOKENS (MFMA B operand) go through LDS: per chunk 256 rows x 128 bytes, 144-byte row stride (the 32-row fragment reads
+//     ds_read_b128 are bank-conflict free), two buffers, one workgroup barrier per chunk.  A thread owns four 16-byte pieces per
+//     chunk; they are REQUESTED two chunks ahead (register double buffer: a chunk lasts ~2 k cycles per SIMD, an HBM miss longer)
+//     and written to LDS one piece per k-step of the chunk before they are needed.
+//   * WEIGHTS (MFMA A operand) never touch LDS: every wave owns 32 output columns and streams exactly its own fragments from a
+//     pre-packed, fragment-ordered image (xm3d_gemm_pack_weight) through L2 into an 8-deep register ring, one 16-byte load per
+//     lane and k-step.  No wave waits for another wave's loads.
+//   * v_mfma_f32_32x32x16_bf16, weights as A (rows = output columns), tokens as B: a lane's accumulator registers are 16
+//     CONSECUTIVE output columns of one token (the packing permutes the rows so), i.e. two 16-byte stores per 32 x 32 tile, and for
+//     GEGLU the value / gate halves of a column pair sit in lanes l and l + 32 of one wave (the packing interleaves 16 value
+//     columns with their 16 gate columns per row block): one cross-half exchange, no second pass over a (M, 2 N_out) tensor.
+// Two chunks are unrolled per loop iteration so that ring slots and piece registers are static.
+// Bound: MFMA for K >= 1024 (CLIP, UNet mid levels); HBM for the 320-wide level (2 M K N flop over 2 M (K + N) bytes = 160 flop/B).
+// Algorithmic FLOP = 2 M K N; bytes = M (K + N_out [+ N_out residual]) * 2 + N K * 2.
+#include <type_traits>
+
+#include "common.h"
+
+namespace xm3d {
+
+typedef float gm_f32x16 __attribute__((ext_vector_type(16)));
+typedef __bf16 gm_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int GM_MT = 256;               // token rows per workgroup
+constexpr int GM_KC = 64;                // K per chunk
+constexpr int GM_PSTR = 144;             // bytes per staged row: 64 bf16 + 16 pad
+constexpr int GM_ASZ = GM_MT * GM_PSTR;  // bytes per LDS buffer
+constexpr int GM_LDS = 2 * GM_ASZ;
+constexpr int GM_D = 8;                  // weight ring depth in k-steps (= two chunks)
+
+enum { GM_ACT_NONE = 0, GM_ACT_GELU = 1, GM_ACT_QUICK_GELU = 2, GM_ACT_GEGLU = 3 };
+
+struct GemmArgs {
+    const __bf16* x;         // (M, K), row stride ldx elements
+    const __bf16* wp;        // packed weights (xm3d_gemm_pack_weight)
+    const float* bias;       // (N) or null; GEGLU: (2 N_out), value half first
+    const __bf16* residual;  // (M, N_out), row stride ldr, or null
+    __bf16* out;             // (M, N_out), row stride ldo
+    int M, K, N;             // N = rows of W (GEGLU: 2 N_out)
+    int ldx, ldr, ldo;
+    int nct;                 // column tiles
+};
+
+// GELU(x) = x/2 (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, two hardware transcendentals)
+// instead of erff's branchy polynomial: the epilogue of a GEGLU tile evaluates it 128 times per lane
+__device__ __forceinline__ float gm_gelu(float x) {
+    const float z = fabsf(x) * 0.70710678118654752f;
+    const float t = __builtin_amdgcn_rcpf(fmaf(0.3275911f, z, 1.f));
+    const float p = t * fmaf(t, fmaf(t, fmaf(t, fmaf(t, 1.061405429f, -1.453152027f), 1.421413741f), -0.284496736f), 0.254829592f);
+    const float e = 1.f - p * __builtin_amdgcn_exp2f(-1.4426950408889634f * z * z);  // erf(|x| / sqrt 2)
+    return 0.5f * x * (1.f + copysignf(e, x));
+}
+
+template <int CT, int ACT>
+__global__ __launch_bounds__(512) void k_gemm(const GemmArgs a) {
+    constexpr int NT = CT == 256 ? 8 : 4;  // 32-token tiles per wave
+    constexpr int NG = NT / 4;             // groups of 4 MFMAs per k-step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wb = CT == 256 ? wave : wave >> 1;        // 32-column row block of this wave inside the tile
+    const int nbase = CT == 128 ? 4 * (wave & 1) : 0;   // first 32-token tile of this wave
+    const int l31 = lane & 31, h = lane >> 5;
+
+    int bid;  // XCD-aware order (speed only): an XCD's L2 sees a contiguous run of tiles; column tiles of one row tile are adjacent
+    {
+        const int n = gridDim.x, i = blockIdx.x, xcd = i & 7, qd = n >> 3, r = n & 7;
+        bid = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (i >> 3);
+    }
+    const int ct = bid % a.nct, mt = bid / a.nct;
+    const int row0 = mt * GM_MT, M = a.M;
+    const int nch = a.K / GM_KC, nk = nch * 4;
+    // N that is not a multiple of the column tile (UNet: 320, 960 with CT = 128): the row blocks past N in the last tile belong to
+    // waves that only stage tokens - no weight stream, no fragment reads, no MFMAs (their SIMD's other wave runs alone)
+    const int gblk = ct * (CT / 32) + wb;  // global 32-row block of W
+    const bool active = gblk * 32 < a.N;
+
+    // ---- weight stream of this wave: 1 KiB (64 lanes x 16 bytes = one A fragment) per k-step, contiguous
+    const char* const wstream = reinterpret_cast<const char*>(a.wp) + (int64_t(ct) * (CT / 32) + wb) * nk * 1024 + lane * 16;
+    gm_bf16x8 wr[GM_D];
+#pragma unroll
+    for (int i = 0; i < GM_D; ++i) wr[i] = *reinterpret_cast<const gm_bf16x8*>(wstream + int64_t(i < nk ? i : nk - 1) * 1024);
+
+    // ---- token staging: thread owns the 16-byte piece (row prow + 64 r, channels 8 kc .. 8 kc + 7) of every chunk, r = 0 .. 3.
+    // Rows past M read row M - 1 (their results are never stored)
+    const int kc = tid & 7, prow = tid >> 3;
+    const __bf16* asrc[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+        const int row = row0 + prow + 64 * r;
+        asrc[r] = a.x + int64_t(row < M ? row : M - 1) * a.ldx + kc * 8;
+    }
+    char* const a_wr = smem + prow * GM_PSTR + kc * 16;  // + r * 64 * GM_PSTR + buffer
+    gm_u32x4 raw[2][4];
+    auto a_load = [&](int set, int c) __attribute__((always_inline)) {
+        const int c0 = (c < nch ? c : nch - 1) * GM_KC;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) raw[set][r] = *reinterpret_cast<const gm_u32x4*>(asrc[r] + c0);
+    };
+
+    // tokens as B operand: row (nbase + n) * 32 + l31 of the tile, 16-byte granule 2 ks + h
+    const char* const xbase = smem + (nbase * 32 + l31) * GM_PSTR + h * 16;
+
+    gm_f32x16 acc[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
+
+    // ---- prologue: chunk 0 into buffer 0, chunk 1 requested
+    a_load(0, 0);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<gm_u32x4*>(a_wr + r * 64 * GM_PSTR) = raw[0][r];
+    a_load(1, 1);
+    __syncthreads();
+
+    // chunk c (parity P = c & 1): MFMAs on LDS buffer P; the pieces of chunk c + 1 (registers raw[1 - P], requested during chunk
+    // c - 1) go to buffer 1 - P, one per k-step; the pieces of chunk c + 2 are requested into raw[P]
+    auto chunk = [&](int c, auto par_tag, auto act_tag) __attribute__((always_inline)) {
+        constexpr int P = decltype(par_tag)::value;
+        constexpr bool ACTV = decltype(act_tag)::value;  // a wave past N only stages (one branch per chunk, straight-line bodies)
+        const char* const xl = xbase + P * GM_ASZ;
+        char* const anext = a_wr + (1 - P) * GM_ASZ;
+        gm_bf16x8 xf[2][4];
+        constexpr int XS = 4 * NG;  // x-sets (4 token tiles each) per chunk
+        auto x_load = [&](int xs, int s) __attribute__((always_inline)) {
+            const int ks = xs / NG, half = xs % NG;
+#pragma unroll
+            for (int n = 0; n < 4; ++n) xf[s][n] = *reinterpret_cast<const gm_bf16x8*>(xl + (half * 4 + n) * 32 * GM_PSTR + ks * 32);
+        };
+        if (ACTV) x_load(0, 0);
+        a_load(P, c + 2);
+#pragma unroll
+        for (int g = 0; g < XS; ++g) {
+            const int ks = g / NG, half = g % NG;
+            __builtin_amdgcn_sched_barrier(0);
+            if (ACTV && g + 1 < XS) x_load(g + 1, (g + 1) & 1);
+            __builtin_amdgcn_sched_barrier(0);
+            if (half == 0) *reinterpret_cast<gm_u32x4*>(anext + ks * 64 * GM_PSTR) = raw[1 - P][ks];
+            if (ACTV) {
+#pragma unroll
+                for (int n = 0; n < 4; ++n)
+                    acc[half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[P * 4 + ks], xf[g & 1][n], acc[half * 4 + n], 0, 0, 0);
+                if (half == NG - 1) {  // the ring slot is free: request the fragment of k-step + 8
+                    __builtin_amdgcn_sched_barrier(0);
+                    const int jn = c * 4 + ks + GM_D;
+                    wr[P * 4 + ks] = *reinterpret_cast<const gm_bf16x8*>(wstream + int64_t(jn < nk ? jn : nk - 1) * 1024);
+                }
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // buffer hand-over: my LDS stores are done, nobody reads buffer P any more.  Raw barrier: __syncthreads() would also drain
+        // vmcnt, i.e. the weight ring and the requested pieces
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        asm volatile("" ::: "memory");
+    };
+    using P0 = std::integral_constant<int, 0>;
+    using P1 = std::integral_constant<int, 1>;
+    int c = 0;
+    if (active) {
+        for (; c + 1 < nch; c += 2) {
+            chunk(c, P0{}, std::true_type{});
+            chunk(c + 1, P1{}, std::true_type{});
+        }
+        if (c < nch) chunk(c, P0{}, std::true_type{});
+    } else {
+        for (; c + 1 < nch; c += 2) {
+            chunk(c, P0{}, std::false_type{});
+            chunk(c + 1, P1{}, std::false_type{});
+        }
+        if (c < nch) chunk(c, P0{}, std::false_type{});
+    }
+
+    // ---- epilogue.  Accumulator register i of lane (token l31 of tile n, half h) = column 16 h + i of the wave's row block
+    if constexpr (ACT == GM_ACT_GEGLU) {
+        // rows 0 .. 15 of the block are value columns 16 gblk + i, rows 16 .. 31 their gate columns: half 0 holds values, half 1
+        // gates.  Exchange so that half 0 finishes columns 0 .. 7 and half 1 columns 8 .. 15 of the 16 (one 16-byte store each)
+        const int nout = a.N >> 1;
+        const int col = gblk * 16 + 8 * h;
+        if (active) {
+            float bv[8], bg[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                bv[i] = a.bias ? a.bias[col + i] : 0.f;
+                bg[i] = a.bias ? a.bias[nout + col + i] : 0.f;
+            }
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int row = row0 + (nbase + n) * 32 + l31;
+                gm_bf16x8 pk;
+                uint4 rr = make_uint4(0, 0, 0, 0);
+                if (a.residual && row < M) rr = *reinterpret_cast<const uint4*>(a.residual + int64_t(row) * a.ldr + col);
+                const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
+#pragma unroll
+                for (int i = 0; i < 8; ++i) {
+                    const float send = h ? acc[n][i] : acc[n][8 + i];  // h = 1 sends gates 0..7, h = 0 sends values 8..15
+                    const float recv = __shfl_xor(send, 32);
+                    const float val = (h ? recv : acc[n][i]) + bv[i];
+                    const float gate = (h ? acc[n][8 + i] : recv) + bg[i];
+                    const float res = __uint_as_float((i & 1) ? (rw[i >> 1] & 0xFFFF0000u) : (rw[i >> 1] << 16));
+                    pk[i] = (__bf16)(val * gm_gelu(gate) + res);
+                }
+                if (row < M) *reinterpret_cast<gm_bf16x8*>(a.out + int64_t(row) * a.ldo + col) = pk;
+            }
+        }
+    } else {
+        const int col = gblk * 32 + 16 * h;
+        if (active) {
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = a.bias ? *reinterpret_cast<const float4*>(a.bias + col + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int row = row0 + (nbase + n) * 32 + l31;
+                uint4 rr[2] = {make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0)};
+                if (a.residual && row < M) {
+                    rr[0] = *reinterpret_cast<const uint4*>(a.residual + int64_t(row) * a.ldr + col);
+                    rr[1] = *reinterpret_cast<const uint4*>(a.residual + int64_t(row) * a.ldr + col + 8);
+                }
+                const unsigned rw[8] = {rr[0].x, rr[0].y, rr[0].z, rr[0].w, rr[1].x, rr[1].y, rr[1].z, rr[1].w};
+                gm_bf16x8 pk[2];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4] = {acc[n][4 * q] + bq[q].x, acc[n][4 * q + 1] + bq[q].y, acc[n][4 * q + 2] + bq[q].z, acc[n][4 * q + 3] + bq[q].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (ACT == GM_ACT_GELU) v[j] = gm_gelu(v[j]);
+                        if constexpr (ACT == GM_ACT_QUICK_GELU)
+                            v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[j]));
+                    }
+                    v[0] += __uint_as_float(rw[2 * q] << 16);
+                    v[1] += __uint_as_float(rw[2 * q] & 0xFFFF0000u);
+                    v[2] += __uint_as_float(rw[2 * q + 1] << 16);
+                    v[3] += __uint_as_float(rw[2 * q + 1] & 0xFFFF0000u);
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) pk[q >> 1][(q & 1) * 4 + j] = (__bf16)v[j];
+                }
+                if (row < M) {
+                    *reinterpret_cast<gm_bf16x8*>(a.out + int64_t(row) * a.ldo + col) = pk[0];
+                    *reinterpret_cast<gm_bf16x8*>(a.out + int64_t(row) * a.ldo + col + 8) = pk[1];
+                }
+            }
+        }
+    }
+}
+
+// W (N, K) row-major, bf16 or f32 -> fragment order: [32-row block][k-step][lane][8 bf16]; MFMA row rho of a block = block row
+// 16 ((rho >> 2) & 1) + (rho & 3) + 4 (rho >> 3) (so that a lane's accumulator registers are 16 consecutive block rows); block row
+// -> row of W: plain: 32 blk + r; GEGLU: r < 16: value row 16 blk + r, else gate row N/2 + 16 blk + (r - 16).  Rows past N
+// (padding of the last column tile) are zero.
+template <typename T>
+__global__ void k_gemm_pack(const T* __restrict__ w, int N, int K, int nblk, int geglu, __bf16* __restrict__ out) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // one 16-byte output vector per thread
+    const int nk = K / 16;
+    if (i >= int64_t(nblk) * nk * 64) return;
+    const int l = int(i & 63);
+    const int j = int((i >> 6) % nk);
+    const int blk = int((i >> 6) / nk);
+    const int rho = l & 31;
+    const int r = 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
+    int row;
+    bool valid;
+    if (geglu) {
+        const int half = N >> 1;
+        row = r < 16 ? 16 * blk + r : half + 16 * blk + (r - 16);
+        valid = 16 * blk + (r & 15) < half;
+    } else {
+        row = 32 * blk + r;
+        valid = row < N;
+    }
+    const int k = j * 16 + (l >> 5) * 8;
+    gm_bf16x8 o;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) o[e] = valid ? (__bf16)float(w[int64_t(row) * K + k + e]) : (__bf16)0.f;
+    reinterpret_cast<gm_bf16x8*>(out)[i] = o;
+}
+
+template <int CT, int ACT>
+static int launch_gemm(const GemmArgs& a, hipStream_t s) {
+    static bool configured = false;
+    if (!configured) {
+        XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<CT, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, GM_LDS));
+        configured = true;
+    }
+    const int grid = ((a.M + GM_MT - 1) / GM_MT) * a.nct;
+    hipLaunchKernelGGL((k_gemm<CT, ACT>), dim3(grid), dim3(512), GM_LDS, s, a);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+template <int CT>
+static int dispatch_gemm(const GemmArgs& a, int act, hipStream_t s) {
+    switch (act) {
+        case GM_ACT_NONE: return launch_gemm<CT, GM_ACT_NONE>(a, s);
+        case GM_ACT_GELU: return launch_gemm<CT, GM_ACT_GELU>(a, s);
+        case GM_ACT_QUICK_GELU: return launch_gemm<CT, GM_ACT_QUICK_GELU>(a, s);
+        default: return launch_gemm<CT, GM_ACT_GEGLU>(a, s);
+    }
+}
+
+}  // namespace xm3d
+
+using namespace xm3d;
+
+// column tile for N rows of W: 256 when that wastes nothing (or N is large), else 128; the packed image is padded to whole tiles
+extern "C" int xm3d_gemm_col_tile(int n_rows) { return n_rows % 256 == 0 ? 256 : 128; }
+
+extern "C" int64_t xm3d_gemm_packed_elems(int n_rows, int K, int col_tile) {
+    const int64_t npad = (int64_t(n_rows) + col_tile - 1) / col_tile * col_tile;
+    return npad * K;
+}
+
+extern "C" int xm3d_gemm_pack_weight(const void* w, int w_is_f32, int N, int K, int act, int col_tile, void* packed, void* stream) {
+    XM3D_REQUIRE(w && packed, "gemm_pack_weight: null pointer");
+    XM3D_REQUIRE(K > 0 && K % GM_KC == 0, "gemm_pack_weight: K %d is not a multiple of %d", K, GM_KC);
+    XM3D_REQUIRE(col_tile == 128 || col_tile == 256, "gemm_pack_weight: column tile %d unsupported", col_tile);
+    XM3D_REQUIRE(N > 0 && N % 32 == 0, "gemm_pack_weight: N %d is not a multiple of 32", N);
+    XM3D_REQUIRE(act >= 0 && act <= 3, "gemm_pack_weight: unknown epilogue %d", act);
+    const int geglu = act == GM_ACT_GEGLU;
+    const int nblk = int((int64_t(N) + col_tile - 1) / col_tile) * (col_tile / 32);
+    const int64_t total = int64_t(nblk) * (K / 16) * 64;
+    if (w_is_f32)
+        hipLaunchKernelGGL(k_gemm_pack<float>, dim3(unsigned((total + 255) / 256)), dim3(256), 0, as_stream(stream), static_cast<const float*>(w), N, K,
+                           nblk, geglu, static_cast<__bf16*>(packed));
+    else
+        hipLaunchKernelGGL(k_gemm_pack<__bf16>, dim3(unsigned((total + 255) / 256)), dim3(256), 0, as_stream(stream), static_cast<const __bf16*>(w), N,
+                           K, nblk, geglu, static_cast<__bf16*>(packed));
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+extern "C" int xm3d_gemm_bf16(const void* x, int64_t M, int K, int64_t ldx, const void* wpacked, int N, int col_tile, const float* bias, int act,
+                              const void* residual, int64_t ldr, void* out, int64_t ldo, void* stream) {
+    XM3D_REQUIRE(x && wpacked && out, "gemm_bf16: null pointer");
+    XM3D_REQUIRE(M > 0 && M < (int64_t(1) << 31) - GM_MT, "gemm_bf16: M out of range");
+    XM3D_REQUIRE(K > 0 && K % GM_KC == 0, "gemm_bf16: K %d is not a multiple of %d", K, GM_KC);
+    XM3D_REQUIRE(col_tile == 128 || col_tile == 256, "gemm_bf16: column tile %d unsupported", col_tile);
+    XM3D_REQUIRE(N > 0 && N % 32 == 0, "gemm_bf16: N %d is not a multiple of 32", N);
+    XM3D_REQUIRE(act >= 0 && act <= 3, "gemm_bf16: unknown epilogue %d", act);
+    const int nout = act == GM_ACT_GEGLU ? N / 2 : N;
+    XM3D_REQUIRE(ldx >= K && ldo >= nout && (!residual || ldr >= nout) && ldx % 8 == 0 && ldo % 8 == 0 && ldr % 8 == 0 &&
+                     ldx < (int64_t(1) << 31) && ldo < (int64_t(1) << 31) && ldr < (int64_t(1) << 31),
+                 "gemm_bf16: row strides must cover the row and be multiples of 8 elements");
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(out) |
+                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+                 "gemm_bf16: tensors must be 16-byte aligned");
+    GemmArgs a;
+    a.x = static_cast<const __bf16*>(x);
+    a.wp = static_cast<const __bf16*>(wpacked);
+    a.bias = bias;
+    a.residual = static_cast<const __bf16*>(residual);
+    a.out = static_cast<__bf16*>(out);
+    a.M = int(M), a.K = K, a.N = N;
+    a.ldx = int(ldx), a.ldr = int(ldr), a.ldo = int(ldo);
+    a.nct = (N + col_tile - 1) / col_tile;
+    const int64_t grid = ((M + GM_MT - 1) / GM_MT) * a.nct;
+    XM3D_REQUIRE(grid < (int64_t(1) << 31), "gemm_bf16: grid too large");
+    return col_tile == 256 ? dispatch_gemm<256>(a, act, as_stream(stream)) : dispatch_gemm<128>(a, act, as_stream(stream));
+}

@@ -508,6 +508,71 @@ def conv3x3_pack_weight(weight):
     return packed, tile
 
 
+# ---- linear layer / 1x1 convolution with fused epilogue (csrc/gemm.hip)
+GEMM_ACTS = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "geglu": 3}
+
+
+def gemm_supported(x, n_rows, k=None):
+    """x: (..., K) bf16 on the GPU whose rows are contiguous and evenly strided; K % 64, N % 32"""
+    k = x.shape[-1] if k is None else k
+    return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() >= 2 and x.shape[-1] == k and k % 64 == 0 and n_rows % 32 == 0
+            and x.numel() > 0 and _rows_of(x) is not None)
+
+
+def _rows_of(x):
+    """(M, row stride) if x (..., K) is a stack of rows at a constant stride (contiguous tensors and column slices of one), else None"""
+    if x.stride(-1) != 1:
+        return None
+    if x.dim() == 2:
+        ld = x.stride(0)
+        return (x.shape[0], ld) if ld % 8 == 0 and ld >= x.shape[1] else None
+    ld = x.stride(-2)
+    expect = ld
+    for d in range(x.dim() - 2, -1, -1):
+        if x.shape[d] != 1 and x.stride(d) != expect:
+            return None
+        expect *= x.shape[d]
+    return (x.numel() // x.shape[-1], ld) if ld % 8 == 0 and ld >= x.shape[-1] else None
+
+
+def gemm_pack_weight(weight, act=None):
+    """Linear / 1x1 Conv2d weight (N, K[, 1, 1]), f32 or bf16 -> (packed bf16 tensor, column tile) for gemm(..., act=act).
+    The packed image depends on `act` only through "geglu" (value / gate rows interleaved)."""
+    w = weight.detach().reshape(weight.shape[0], -1)
+    n, k = w.shape
+    if k % 64 != 0 or n % 32 != 0 or w.dtype not in (torch.float32, torch.bfloat16):
+        raise TypeError(f"gemm_pack_weight: unsupported weight {tuple(weight.shape)} {weight.dtype}")
+    w = w.contiguous()
+    tile = lib().xm3d_gemm_col_tile(n)
+    packed = torch.empty(lib().xm3d_gemm_packed_elems(n, k, tile), dtype=torch.bfloat16, device=w.device)
+    check(lib().xm3d_gemm_pack_weight(_ptr(w), int(w.dtype == torch.float32), n, k, GEMM_ACTS[act], tile, _ptr(packed), _stream()), "xm3d_gemm_pack_weight")
+    return packed, tile
+
+
+def gemm(x, packed, n_rows, tile, bias=None, act=None, residual=None):
+    """out = act(x @ W^T + bias) (+ residual) over the last dimension of x; "geglu": out = (x Wv^T + bv) * GELU(x Wg^T + bg) with
+    W = [Wv; Wg] (n_rows = 2 * out features).  x (..., K) bf16, bias f32 (n_rows) or None, residual like the output or None."""
+    k = x.shape[-1]
+    rows = _rows_of(x) if x.is_cuda and x.dtype == torch.bfloat16 else None
+    if rows is None or k % 64 != 0:
+        raise TypeError(f"gemm: unsupported input {tuple(x.shape)} {x.dtype} strides {x.stride()}")
+    m, ldx = rows
+    a = GEMM_ACTS[act]
+    nout = n_rows // 2 if a == 3 else n_rows
+    out = torch.empty(x.shape[:-1] + (nout,), dtype=torch.bfloat16, device=x.device)
+    ldr = 0
+    if residual is not None:
+        rr = _rows_of(residual) if residual.dtype == torch.bfloat16 and residual.shape == out.shape else None
+        if rr is None:
+            raise TypeError("gemm: residual must be a bf16 tensor of the output's shape with evenly strided rows")
+        ldr = rr[1]
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != n_rows):
+        raise TypeError("gemm: bias must be a contiguous f32 (n_rows,) tensor")
+    check(lib().xm3d_gemm_bf16(_ptr(x), m, k, ldx, _ptr(packed), n_rows, tile, _ptr(bias), a, _ptr(residual), ldr, _ptr(out), nout, _stream()),
+          "xm3d_gemm_bf16")
+    return out
+
+
 _CONV_WAVES = int(_os.environ.get("XM3D_CONV_WAVES", "0"))  # A/B switch for bench runs: force one workgroup geometry (0 = per-layer choice)
 
 

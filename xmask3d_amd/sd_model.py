@@ -97,6 +97,59 @@ def plain_conv3x3(conv, x, upsample=False):
                        stats_groups=32 if (conv.out_channels // 32) % 4 == 0 else None)
 
 
+# ---- linear layers / 1x1 convolutions on the HIP GEMM (csrc/gemm.hip, xm3d_gemm_bf16)
+_GEMM_LIBRARY = os.environ.get("XM3D_GEMM", "hip") == "library"  # A/B switch: every projection back on torch (hipBLASLt)
+
+
+def gemm_ok(x, n_rows, act=None, fused_residual=False):
+    """bf16 inference rows on a (K, N) where k_gemm beats the library chain it replaces (tools/gemm_bench.py on MI355X, 20 views,
+    profiles/r03_gemm_bench.log): the HBM-bound projections of the 64^2 / 32^2 UNet levels, the VAE AttnBlock and the cross
+    attention's context projections (K <= 768), plus K = 1280 when a residual add rides in the epilogue.  The MFMA-bound ones
+    (K >= 1280, the 640 / 1280-wide GEGLU, mask-CLIP) stay on hipBLASLt, which is 1.1 - 2 x faster there."""
+    if _GEMM_LIBRARY or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.bfloat16:
+        return False
+    k = x.shape[-1]
+    if act == "geglu":
+        wins = k <= 320
+    else:
+        wins = k <= 768 or (fused_residual and k <= 1280 and n_rows <= 320)
+    return wins and ops.gemm_supported(x, n_rows, k)
+
+
+def _packed_lin(mods, act=None):
+    """(packed weight, column tile, f32 bias or None, rows) of one frozen Linear / 1x1 Conv2d, or of several stacked along the
+    output dimension (one GEMM for q, k, v); built once per weight storage and epilogue"""
+    mods = list(mods) if isinstance(mods, (list, tuple)) else [mods]
+    key = tuple((m.weight.data_ptr(), m.weight._version, m.weight.dtype) for m in mods)
+    cache = mods[0].__dict__.setdefault("_xm3d_gemm", {})
+    c = cache.get((len(mods), act))
+    if c is None or c[0] != key:
+        w = torch.cat([m.weight.detach().reshape(m.weight.shape[0], -1) for m in mods], 0)
+        packed, tile = ops.gemm_pack_weight(w, act)
+        bias = None
+        if any(m.bias is not None for m in mods):
+            bias = torch.cat([m.bias.detach().float() if m.bias is not None else torch.zeros(m.weight.shape[0], device=w.device)
+                              for m in mods]).contiguous()
+        c = cache[(len(mods), act)] = (key, packed, tile, bias, w.shape[0])
+    return c[1:]
+
+
+def lin(mods, x, act=None, residual=None):
+    """act(x @ W^T + b) (+ residual) over the last dimension in one launch; mods: a Linear / 1x1 Conv2d or a list of them (stacked)"""
+    packed, tile, bias, n = _packed_lin(mods, act)
+    return ops.gemm(x, packed, n, tile, bias=bias, act=act, residual=residual)
+
+
+def tokens_of(x):
+    """channels-last (B, C, H, W) -> its (B, H*W, C) token rows, a view"""
+    return x.permute(0, 2, 3, 1).reshape(x.shape[0], -1, x.shape[1])
+
+
+def image_of(t, h, w):
+    """(B, H*W, C) contiguous token rows -> the channels-last (B, C, H, W) tensor on the same storage"""
+    return t.view(t.shape[0], h, w, t.shape[2]).permute(0, 3, 1, 2)
+
+
 def bias_residual(skip, h, bias):
     """skip + h + bias[c] in one pass (skip may be None); the GroupNorm(32) statistics of the result are taken on the way - every
     consumer of a block output in these nets that normalises it uses 32 groups (group_norm())"""
@@ -403,9 +456,23 @@ class CrossAttention(nn.Module):
         self.to_out = nn.Sequential(nn.Linear(inner, query_dim), nn.Dropout(0.0))
 
     def forward(self, x, context=None):
+        self_attn = context is None
         context = x if context is None else context
         b, n, _ = x.shape
         h = self.heads
+        inner = self.to_q.out_features
+        if gemm_ok(x, 3 * inner if self_attn else inner) and gemm_ok(context, 2 * inner) and inner % (8 * h) == 0:
+            # HIP GEMMs: q, k, v of the self attention from ONE pass over x (the attention kernel reads them as column slices of the
+            # fused projection), k, v of the cross attention from one pass over the context
+            if self_attn:
+                qkv = lin([self.to_q, self.to_k, self.to_v], x)
+                q, k, v = (qkv[..., i * inner:(i + 1) * inner].unflatten(-1, (h, -1)) for i in range(3))
+            else:
+                q = lin(self.to_q, x).view(b, n, h, -1)
+                kv = lin([self.to_k, self.to_v], context)
+                k, v = (kv[..., i * inner:(i + 1) * inner].unflatten(-1, (h, -1)) for i in range(2))
+            if ops.attention_supported(q, k, v):
+                return lin(self.to_out[0], ops.attention(q, k, v).view(b, n, -1))
         q = self.to_q(x).view(b, n, h, -1)
         k = self.to_k(context).view(b, context.shape[1], h, -1)
         v = self.to_v(context).view(b, context.shape[1], h, -1)
@@ -437,8 +504,15 @@ class FeedForward(nn.Module):
         super().__init__()
         self.net = nn.Sequential(GEGLU(dim, dim * mult), nn.Dropout(0.0), nn.Linear(dim * mult, dim))
 
-    def forward(self, x):
-        return self.net(x)
+    def forward(self, x, residual=None):
+        """net(x) (+ residual).  Inference: GEGLU in the epilogue of its projection where that wins (no (M, 8 dim) intermediate),
+        the residual add in the epilogue of the output projection"""
+        g, out = self.net[0], self.net[2]
+        y = lin(g.proj, x, act="geglu") if gemm_ok(x, g.proj.out_features, "geglu") else g(x)
+        if gemm_ok(y, out.out_features, fused_residual=residual is not None):
+            return lin(out, y, residual=residual)
+        y = out(y)
+        return y if residual is None else y + residual
 
 
 class BasicTransformerBlock(nn.Module):
@@ -457,7 +531,7 @@ class BasicTransformerBlock(nn.Module):
             h, x = ops.layer_norm(x, n2.weight, n2.bias, n2.eps, delta=a.contiguous(), want_sum=True)
             a = self.attn2(h, context)
             h, x = ops.layer_norm(x, n3.weight, n3.bias, n3.eps, delta=a.contiguous(), want_sum=True)
-            return self.ff(h) + x
+            return self.ff(h, residual=x)
         x = self.attn1(self.norm1(x)) + x
         x = self.attn2(self.norm2(x), context) + x
         return self.ff(self.norm3(x)) + x
@@ -473,9 +547,18 @@ class SpatialTransformer(nn.Module):
 
     def forward(self, x, context):
         b, c, h, w = x.shape
-        y = self.proj_in(gn_act(self.norm, x)).flatten(2).transpose(1, 2)
-        for blk in self.transformer_blocks:
-            y = blk(y, context.to(y.dtype))
+        xn = gn_act(self.norm, x)
+        if fused_nhwc(xn) and gemm_ok(tokens_of(xn), self.proj_in.out_channels) and self.proj_out.out_channels % 32 == 0:
+            # 1x1 convolutions of channels-last images are GEMMs over their token rows: proj_in + bias, proj_out + bias + skip
+            y = lin(self.proj_in, tokens_of(xn))
+            for blk in self.transformer_blocks:
+                y = blk(y, context.to(y.dtype))
+            if gemm_ok(y, self.proj_out.out_channels):
+                return image_of(lin(self.proj_out, y, residual=tokens_of(x)), h, w)
+        else:
+            y = self.proj_in(xn).flatten(2).transpose(1, 2)
+            for blk in self.transformer_blocks:
+                y = blk(y, context.to(y.dtype))
         y = y.transpose(1, 2).reshape(b, -1, h, w)
         if fused_nhwc(x) and fused_nhwc(y):
             return bias_residual(x, conv_nobias(self.proj_out, y), self.proj_out.bias)
