@@ -304,6 +304,23 @@ int xm3d_softmax_rows_f32_bf16(const float* scores, int64_t rows, int32_t cols, 
 int xm3d_attn_mask_bias(const void* logits, int32_t in_dtype, int64_t maps, int32_t H, int32_t W, int32_t h, int32_t w, void* out,
                         int32_t out_dtype, void* stream);
 
+/* ---- prediction heads over mask_features (maskhead.hip): forward_prediction_heads + the mask handling of the masked transformer
+ * decoder's forward + MaskPooling, models/modeling/meta_arch/odise.py:395,445-491,509-547 (einsum "bqc,bchw->bqhw", bilinear shrink ->
+ * sigmoid -> threshold -> empty-mask rule -> additive mask; hard mask pooling einsum "bchw,bqhw->bqc").
+ *   xm3d_mask_logits_bias : mask_embed (B, Q, 256) bf16, mask_features (B, H*W, 256) bf16 (channels-last image) ->
+ *       logits (B, Q, H, W) bf16 or NULL (not wanted: only the rows the bias needs are computed), and
+ *       bias (B, Q, h*w) f32 (bias_dtype 0) / bf16 (1) = 0 / -inf additive attention mask for the (h, w) level, or NULL.
+ *       Constraints: Q <= 64, mask_dim 256, (H, W) -> (h, w) a shrink by an even integer factor, W % 32 == 0, 32 % (W / w) == 0.
+ *   xm3d_mask_pool : logits (B, Q, H*W) bf16 + mask_features -> pooled_partial (chunks, B, Q, 256) f32 = per pixel chunk the sum of the
+ *       feature rows of the pixels with logit > 0 (sigmoid > 0.5), count_partial (chunks, B, Q) f32 = their number, chunks =
+ *       xm3d_mask_pool_chunks(H*W); every entry is written.  MaskPooling = sum_chunks pooled / (sum_chunks count + 1e-8).
+ *   Launched on `stream`, no host synchronisation. */
+int xm3d_mask_logits_bias(const void* mask_embed, const void* mask_features, int64_t B, int32_t Q, int32_t C, int32_t H, int32_t W, void* logits,
+                          int32_t h, int32_t w, void* bias, int32_t bias_dtype, void* stream);
+int32_t xm3d_mask_pool_chunks(int64_t HW);
+int xm3d_mask_pool(const void* logits, const void* mask_features, int64_t B, int32_t Q, int32_t C, int64_t HW, float* pooled_partial,
+                   float* count_partial, void* stream);
+
 /* ---------------------------------------------------------------------------
  * Fused softmax attention forward, bf16 in / f32 softmax and accumulation / bf16 out (replaces the library attention behind
  * torch.nn.functional.scaled_dot_product_attention at the reference's call sites: ldm CrossAttention reached from

@@ -15,6 +15,8 @@ from __future__ import annotations
 
 import math
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -358,6 +360,13 @@ class MaskPooling(nn.Module):
         self.hard_pooling, self.mask_threshold = hard_pooling, mask_threshold
 
     def forward(self, x, mask):
+        if self.hard_pooling and self.mask_threshold == 0.5 and x.is_cuda and not torch.is_grad_enabled() and mask.dtype == torch.bfloat16 \
+                and mask.is_contiguous() and mask.shape[1] <= 64 and x.shape[1] == 256 and (x.shape[2] * x.shape[3]) % 16 == 0 \
+                and x.dtype == torch.bfloat16 and x.is_contiguous(memory_format=torch.channels_last) and x.dim() == 4:
+            from . import ops
+
+            # sigmoid(m) > 0.5 <=> m > 0: threshold in registers, masked feature sums on the matrix cores (xm3d_mask_pool), f32 mean
+            return {"mask_pooled_features": ops.mask_pool(mask.detach(), x)}
         mask = mask.detach().sigmoid()
         if self.hard_pooling:
             mask = (mask > self.mask_threshold).to(mask.dtype)
@@ -479,8 +488,20 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
         # (the class logits of a layer whose pooled embedding is pruned feed nothing either: same switch)
         outputs_class = self.class_embed(decoder_output) if with_embed else None
         mask_embed = self.mask_embed(decoder_output)
-        outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
         extra = {}
+        if mask_embed.is_cuda and not torch.is_grad_enabled() and os.environ.get("XM3D_MASK_HEADS", "hip") != "library":
+            from . import ops
+
+            qdt = torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else mask_embed.dtype
+            if qdt == torch.bfloat16 and ops.mask_heads_supported(mask_embed, mask_features, attn_mask_target_size):
+                # fused heads (csrc/maskhead.hip): logits on the matrix cores + the attention bias from them in one launch; a layer
+                # whose embeddings are pruned (with_embed False: evaluation, 9 of 10 layers) needs only the bias - its logits are
+                # never written, and only the rows the bias reads are computed.  bf16 logits as under autocast.
+                outputs_mask, bias = ops.mask_logits_bias(mask_embed, mask_features, attn_mask_target_size, want_logits=with_embed, bias_dtype=qdt)
+                if self.post_mask_embed is not None and with_embed:
+                    extra.update(self.post_mask_embed(decoder_output, mask_embed, mask_features, outputs_class, outputs_mask))
+                return outputs_class, outputs_mask, bias, extra
+        outputs_mask = torch.einsum("bqc,bchw->bqhw", mask_embed, mask_features)
         if self.post_mask_embed is not None and with_embed:
             extra.update(self.post_mask_embed(decoder_output, mask_embed, mask_features, outputs_class, outputs_mask))
         if outputs_mask.is_cuda and not torch.is_grad_enabled() and outputs_mask.dtype in (torch.float32, torch.bfloat16):

@@ -636,6 +636,47 @@ def attn_mask_bias(logits, size, out_dtype):
     return out
 
 
+def mask_heads_supported(mask_embed, mask_features, size):
+    """the fused prediction heads take: channels-last bf16 mask_features (B, 256, H, W), Q <= 64 queries, an even integer shrink to
+    `size` that divides the kernel's 32-pixel segments; inference only"""
+    if torch.is_grad_enabled() or not mask_features.is_cuda or mask_features.dtype != torch.bfloat16 or mask_features.dim() != 4:
+        return False
+    B, C, H, W = mask_features.shape
+    h, w = int(size[0]), int(size[1])
+    return (C == 256 and mask_features.is_contiguous(memory_format=torch.channels_last) and mask_embed.dim() == 3 and mask_embed.shape[0] == B
+            and mask_embed.shape[1] <= 64 and mask_embed.shape[2] == C and attn_mask_bias_supported((H, W), (h, w)) and W % 32 == 0
+            and 32 % (W // w) == 0)
+
+
+def mask_logits_bias(mask_embed, mask_features, size, want_logits=True, bias_dtype=torch.float32):
+    """einsum("bqc,bchw->bqhw") on the matrix cores + the additive attention bias of the (h, w) level from the logits while they are
+    on chip (see xm3d.h).  -> (logits (B,Q,H,W) bf16 or None, bias (B,Q,h*w) of bias_dtype)"""
+    B, C, H, W = mask_features.shape
+    Q = mask_embed.shape[1]
+    h, w = int(size[0]), int(size[1])
+    me = mask_embed.detach().to(torch.bfloat16).contiguous()
+    logits = torch.empty((B, Q, H, W), dtype=torch.bfloat16, device=me.device) if want_logits else None
+    bias = torch.empty((B, Q, h * w), dtype=bias_dtype, device=me.device)
+    check(lib().xm3d_mask_logits_bias(_ptr(me), _ptr(mask_features), B, Q, C, H, W, _ptr(logits), h, w, _ptr(bias),
+                                      0 if bias_dtype == torch.float32 else 1, _stream()), "xm3d_mask_logits_bias")
+    return logits, bias
+
+
+def mask_pool(logits, mask_features):
+    """MaskPooling with hard masks (sigmoid(logit) > 0.5): (B,Q,H,W) bf16 logits + channels-last bf16 mask_features (B,C,H,W) ->
+    (B,Q,C) f32 mean of the feature rows under each mask (0 for an empty mask, like sum / (0 + 1e-8))"""
+    B, Q, H, W = logits.shape
+    C = mask_features.shape[1]
+    if not (logits.is_cuda and logits.dtype == torch.bfloat16 and logits.is_contiguous() and mask_features.dtype == torch.bfloat16
+            and mask_features.is_contiguous(memory_format=torch.channels_last) and mask_features.shape == (B, C, H, W)):
+        raise TypeError("mask_pool: contiguous bf16 logits (B,Q,H,W) and channels-last bf16 mask_features (B,C,H,W) required")
+    chunks = lib().xm3d_mask_pool_chunks(H * W)
+    pooled = torch.empty((chunks, B, Q, C), dtype=torch.float32, device=logits.device)
+    count = torch.empty((chunks, B, Q), dtype=torch.float32, device=logits.device)
+    check(lib().xm3d_mask_pool(_ptr(logits), _ptr(mask_features), B, Q, C, H * W, _ptr(pooled), _ptr(count), _stream()), "xm3d_mask_pool")
+    return pooled.sum(0) / (count.sum(0).unsqueeze(-1) + 1e-8)
+
+
 def attn_mask_bias_supported(shape, size):
     H, W = shape[-2:]
     h, w = int(size[0]), int(size[1])
