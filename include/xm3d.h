@@ -321,6 +321,22 @@ int32_t xm3d_mask_pool_chunks(int64_t HW);
 int xm3d_mask_pool(const void* logits, const void* mask_features, int64_t B, int32_t Q, int32_t C, int64_t HW, float* pooled_partial,
                    float* count_partial, void* stream);
 
+/* ---- per-point class labels of the inference post-processing (pointclass.hip): run/infer.py:489-507 (base / novel gate) and
+ * :556-612 (fused, 2D-only, 3D-only predictions: F.normalize -> @ text -> * logit_scale -> softmax -> geometric ensemble with the
+ * open-vocabulary probabilities of the point's mask -> gate -> arg-max), one pass over the (Np, K) f32 features.
+ *   x (rows, K) f32 with row stride ldx; row_index (Np) int64 or NULL: point p is computed from row row_index[p];
+ *   text (C, K) f32 UNIT rows, C <= 32, K % 8 == 0, K <= 1024; scale: device f32 scalar or NULL;
+ *   binary_pred (Np) int64 (!= 0: base-predicted point: novel classes are excluded, else base classes); base_mask / novel_mask (C) bool.
+ *   mode 0: label = arg-max over the allowed classes of <x, t_c>                                   (2D-only, 3D-only labels)
+ *   mode 1: p = softmax(scale * <x / |x|, t>); a point inside a mask (masks (Np, Q) bool, at most one set, its first set column q):
+ *           value_c = log(p_c^r po_c^(1-r)), r = base_ratio where overlap[c] else novel_ratio, po = open_p[vid[p], q] ((B, Q, C));
+ *           other points: value_c = p_c; label = arg-max over the allowed classes (first maximum; NaN maximal, as torch.argmax).
+ *   label (Np) int64.  Launched on `stream`, no host synchronisation. */
+int xm3d_point_class(const float* x, int64_t ldx, const int64_t* row_index, int64_t np, const float* text, int32_t C, int32_t K, const float* scale,
+                     const int64_t* binary_pred, const uint8_t* base_mask, const uint8_t* novel_mask, int32_t mode, const uint8_t* masks, int32_t Q,
+                     const int64_t* vid, const float* open_p, const float* overlap, float base_ratio, float novel_ratio, int64_t* label,
+                     void* stream);
+
 /* ---------------------------------------------------------------------------
  * Fused softmax attention forward, bf16 in / f32 softmax and accumulation / bf16 out (replaces the library attention behind
  * torch.nn.functional.scaled_dot_product_attention at the reference's call sites: ldm CrossAttention reached from

@@ -74,6 +74,8 @@ _SIGS = {
     "xm3d_mask_pool_chunks": (ctypes.c_int32, [c_i64]),
     "xm3d_mask_logits_bias": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp]),
     "xm3d_mask_pool": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i32, c_i64, c_vp, c_vp, c_vp]),
+    "xm3d_point_class": (ctypes.c_int, [c_vp, c_i64, c_vp, c_i64, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp,
+                                        ctypes.c_float, ctypes.c_float, c_vp, c_vp]),
     "xm3d_attention_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                           ctypes.c_float, c_vp]),
     "xm3d_attention_fwd_lse": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,

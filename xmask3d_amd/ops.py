@@ -636,6 +636,40 @@ def attn_mask_bias(logits, size, out_dtype):
     return out
 
 
+def point_class_supported(x, text):
+    return (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.stride(1) == 1 and x.stride(0) % 4 == 0 and x.data_ptr() % 16 == 0
+            and text.dtype == torch.float32 and text.dim() == 2 and text.shape[0] <= 32 and text.shape[1] == x.shape[1]
+            and x.shape[1] % 8 == 0 and x.shape[1] <= 1024 and not torch.is_grad_enabled())
+
+
+def point_class(x, text, binary_pred, base_mask, novel_mask, row_index=None, ensemble=None):
+    """Class label per point in one pass over the (rows, K) f32 features x (see xm3d.h, xm3d_point_class).  text (C, K): UNIT rows.
+    binary_pred (Np) int64, base_mask / novel_mask (C) bool.  row_index (Np) int64: point p reads row row_index[p].
+    ensemble None: arg-max of the gated products.  ensemble = (scale 0-dim f32 tensor, masks (Np, Q) bool, vid (Np) int64,
+    open_p (B, Q, C) f32, overlap (C) f32, base_ratio, novel_ratio): the fused prediction chain.  -> (Np) int64"""
+    n = int(binary_pred.shape[0])
+    C, K = text.shape
+    text = text.contiguous()
+    label = torch.empty(n, dtype=torch.int64, device=x.device)
+    if binary_pred.dtype != torch.int64 or base_mask.dtype != torch.bool or novel_mask.dtype != torch.bool:
+        raise TypeError("point_class: binary_pred int64, base_mask / novel_mask bool")
+    if row_index is not None and (row_index.dtype != torch.int64 or row_index.numel() != n):
+        raise TypeError("point_class: row_index must be int64 (Np)")
+    if row_index is None and x.shape[0] != n:
+        raise TypeError("point_class: one feature row per point (or a row_index)")
+    mode, masks, Q, vid, open_p, overlap, scale, br, nr = 0, None, 0, None, None, None, None, 0.0, 0.0
+    if ensemble is not None:
+        scale, masks, vid, open_p, overlap, br, nr = ensemble
+        if masks.dtype != torch.bool or not masks.is_contiguous() or masks.shape[0] != n or vid.dtype != torch.int64 or open_p.dtype != torch.float32 \
+                or overlap.dtype != torch.float32 or scale.dtype != torch.float32 or scale.numel() != 1:
+            raise TypeError("point_class: ensemble = (f32 scalar tensor, bool (Np,Q) masks, int64 vid, f32 open_p (B,Q,C), f32 overlap (C), r_base, r_novel)")
+        mode, Q, open_p = 1, int(masks.shape[1]), open_p.contiguous()
+    check(lib().xm3d_point_class(_ptr(x), x.stride(0), _ptr(row_index), n, _ptr(text), C, K, _ptr(scale), _ptr(binary_pred), _ptr(base_mask),
+                                 _ptr(novel_mask), mode, _ptr(masks), Q, _ptr(vid), _ptr(open_p), _ptr(overlap), float(br), float(nr), _ptr(label),
+                                 _stream()), "xm3d_point_class")
+    return label
+
+
 def mask_heads_supported(mask_embed, mask_features, size):
     """the fused prediction heads take: channels-last bf16 mask_features (B, 256, H, W), Q <= 64 queries, an even integer shrink to
     `size` that divides the kernel's 32-pixel segments; inference only"""

@@ -12,6 +12,8 @@ update of run/infer.py:585-601 equals one gather).  Results follow the reference
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn.functional as F
@@ -280,9 +282,25 @@ def postprocess_scene(cfg, outputs, batch, with_ablations=True):
     vid = batch["point_view"]
     offsets = batch["point_offsets"]
     binary_pred = outputs["binary_pred"]
-    probs = (scale * (F.normalize(outputs["fused_cat"], dim=-1) @ text.t())).softmax(dim=-1)
     open_p = (scale * (F.normalize(outputs["open_embedding_all"], dim=-1) @ text.t())).softmax(dim=-1)   # (B, Q, C)
     masks = outputs["mask_3d_cat"]                     # (Np, Q), pixel-disjoint: at most one query per point
+    fast = (os.environ.get("XM3D_POINT_CLASS", "hip") != "library" and ops.point_class_supported(outputs["fused_cat"], text)
+            and masks.dtype == torch.bool and masks.is_contiguous() and binary_pred.dtype == torch.int64 and torch.is_tensor(scale))
+    if fast:
+        # xm3d_point_class: each (Np, 768) feature table is read once, the (Np, C) logits / probabilities never exist
+        sc = scale.detach().float().reshape(1)
+        pred = ops.point_class(outputs["fused_cat"], text, binary_pred, base, novel,
+                               ensemble=(sc, masks, vid, open_p.float(), overlap, cfg.base_ratio, cfg.novel_ratio))
+        if not with_ablations:
+            return pred, None, None
+        f2d = outputs["feat2d_cat"]
+        n_seg = len(offsets) - 1
+        fill = nearest_valid_fill_segmented(batch["ori_coords"][:, 1:], f2d.sum(1) != 0, vid, n_seg,
+                                            max(offsets[i + 1] - offsets[i] for i in range(n_seg)))
+        pred2d = ops.point_class(f2d, text, binary_pred, base, novel, row_index=fill)
+        pred3d = ops.point_class(outputs["pure3d_cat"], text, binary_pred, base, novel)
+        return pred, pred2d, pred3d
+    probs = (scale * (F.normalize(outputs["fused_cat"], dim=-1) @ text.t())).softmax(dim=-1)
     covered = masks.any(1)
     po = open_p[vid, masks.to(torch.uint8).argmax(1)]
     b = (probs ** cfg.base_ratio * po ** (1 - cfg.base_ratio)).log() * overlap
