@@ -21,3 +21,20 @@ tot = sum(v[1] for v in agg.values()) / 1e6
 print(f"{f}: window {span:.1f} ms, kernels {len(rows)}, busy {tot:.1f} ms ({100*tot/span:.0f}%)")
 for k, (c, t) in sorted(agg.items(), key=lambda kv: -kv[1][1])[:n]:
     print("  %-90s calls %6d avg %8.1f us total %8.2f ms %5.1f%%" % (k, c, t / c / 1e3, t / 1e6, 100 * t / 1e6 / tot))
+# family totals: which implementation the window's device time runs on
+fam = [("xm3d k_conv3x3 (HIP, own)", r"k_conv3x3|k_gn_affine"), ("xm3d k_gemm (HIP, own)", r"k_gemm"), ("xm3d sparse conv (HIP, own)", r"k_spconv"),
+       ("xm3d attention (HIP, own)", r"k_attn_fwd|k_attn_bwd|k_softmax_rows|k_attn_mask"), ("xm3d other kernels (HIP, own)", r"xm3d"),
+       ("MIOpen / CK convolutions (library)", r"^_ZN2ck|ck::|igemm|naive_conv|miopen|Conv"), ("hipBLASLt / rocBLAS GEMMs (library)", r"Cijk|rocblas"),
+       ("rocPRIM (sort / scan)", r"rocprim"), ("aten elementwise / copy / reduce", r"at::native|at_cuda")]
+ft = collections.OrderedDict((n_, 0) for n_, _ in fam)
+ft["other"] = 0
+for k, (c, t) in agg.items():
+    for n_, pat in fam:
+        if re.search(pat, k):
+            ft[n_] += t
+            break
+    else:
+        ft["other"] += t
+print("families:")
+for n_, t in ft.items():
+    print("  %-45s %8.2f ms %5.1f%%" % (n_, t / 1e6, 100 * t / 1e6 / tot))

@@ -186,7 +186,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
         }
         mx = fmaxf(mx, __shfl_xor(mx, 32));
         const float m_new = fmaxf(m_run, mx);
-        const float alpha = exp2f(m_run - m_new);  // 1 when nothing changed, 0 on the first tile
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);  // 1 when nothing changed, 0 on the first tile
         float psum = 0.f;
         bf16x8a pf[2][2];
         if (plain) {
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
-                        const float p = exp2f(fmaf(sacc[kb][8 * s2 + j], scale_log2e, -m_new));
+                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * s2 + j], scale_log2e, -m_new));  // bare v_exp_f32: the argument is <= 0, a denormal result may flush
                         psum += p;
                         pf[kb][s2][j] = (__bf16)p;
                     }
@@ -208,7 +208,7 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
 #pragma unroll
                     for (int j = 0; j < 8; ++j) {
                         const float sc = sacc[kb][8 * s2 + j];
-                        const float p = sc <= ATT_NEG ? 0.f : exp2f(sc - m_new);  // masked scores contribute nothing, also when the row is all masked
+                        const float p = sc <= ATT_NEG ? 0.f : __builtin_amdgcn_exp2f(sc - m_new);  // masked scores contribute nothing, also when the row is all masked
                         psum += p;
                         pf[kb][s2][j] = (__bf16)p;
                     }

@@ -167,7 +167,7 @@ __global__ __launch_bounds__(64 * AB_NW) void k_attn_bwd_dq(const AttnBwdArgs a)
                     const int r = 8 * s2 + j;
                     const int key = t * AB_T + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const float sc = ab_score<BIAS>(sacc[r], a, b, head, q, key);
-                    const float p = sc <= AB_NEG ? 0.f : exp2f(sc - lse);
+                    const float p = sc <= AB_NEG ? 0.f : __builtin_amdgcn_exp2f(sc - lse);
                     dsf[kb][s2][j] = (__bf16)(p * (dpacc[r] - dl) * a.scale);
                 }
         }
@@ -308,7 +308,7 @@ __global__ __launch_bounds__(64 * AB_NW) void k_attn_bwd_dkv(const AttnBwdArgs a
                     const int r = 8 * s2 + j;
                     const int ql = 32 * qb + (r & 3) + 8 * (r >> 2) + 4 * h;  // query row inside the tile
                     const float sc = ab_score<BIAS>(sacc[r], a, b, head, t * AB_T + ql, key);
-                    const float p = sc <= AB_NEG ? 0.f : exp2f(sc - lrow[buf][0][ql]);
+                    const float p = sc <= AB_NEG ? 0.f : __builtin_amdgcn_exp2f(sc - lrow[buf][0][ql]);
                     pf[qb][s2][j] = (__bf16)p;
                     dsf[qb][s2][j] = (__bf16)(p * (dpacc[r] - lrow[buf][1][ql]) * a.scale);
                 }
