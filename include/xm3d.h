@@ -217,8 +217,9 @@ int xm3d_group_norm_nhwc_apply(const void* x, const void* shift, int32_t shift_b
  * in ONE launch on the matrix cores: the normalisation is applied while the input halo tile is staged in LDS (statistics come
  * in as f64 moments), bias / per-sample embedding term / skip connection are added in the epilogue, and the moments of `out`
  * for the NEXT GroupNorm are accumulated there as well.
- *   xm3d_conv3x3_cout_tile(cout)  -> output-channel tile the kernel uses for `cout` (256 or 128; 0 = unsupported)
- *   xm3d_conv3x3_pack_weight      : w_ohwi (cout, 3, 3, cin) bf16 (= Conv2d.weight.permute(0,2,3,1)) -> packed (same byte count):
+ *   xm3d_conv3x3_cout_tile(cout)  -> output-channel tile the kernel uses for `cout` (256 or 128; 0 = unsupported: cout % 32 != 0);
+ *   xm3d_conv3x3_packed_elems     -> bf16 elements of the packed image (cout padded to whole tiles: 320 -> 384)
+ *   xm3d_conv3x3_pack_weight      : w_ohwi (cout, 3, 3, cin) bf16 (= Conv2d.weight.permute(0,2,3,1)) -> packed (xm3d_conv3x3_packed_elems):
  *                                   per (cout tile, 32-row block) one contiguous stream of MFMA A fragments, 1 KiB per k-step
  *   xm3d_conv3x3_nhwc             : x (B, H>>upsample, W>>upsample, cin) bf16; out / residual (B, H, W, cout) bf16.
  *       gn_stats (B, groups, 2) f64 sum / sum of squares of x over each (sample, group), gamma / beta (cin) f32, act = 1 (SiLU) or
@@ -231,9 +232,10 @@ int xm3d_group_norm_nhwc_apply(const void* x, const void* shift, int32_t shift_b
  *       ws: xm3d_conv3x3_ws_bytes(B, cin) bytes of device scratch (the per-(image, channel) affine derived from the moments by a
  *       small kernel in front of the convolution); may be NULL without GroupNorm.
  *       waves: 0 (choose), 8 or 4 - the workgroup geometry, results do not depend on it.
- *   Constraints: H % 8 == 0 (waves 8) or H % 4 == 0 (waves 4), W % 32 == 0, cin % 64 == 0, cout % cout_tile == 0, (cout / groups_out) % 4 == 0, 16-byte aligned tensors.
+ *   Constraints: H % 8 == 0 (waves 8) or H % 4 == 0 (waves 4), W % 32 == 0, cin % 64 == 0, cout % 32 == 0, (cout / groups_out) % 4 == 0, 16-byte aligned tensors.
  *   Launched on `stream`, no host synchronisation. */
 int xm3d_conv3x3_cout_tile(int32_t cout);
+int64_t xm3d_conv3x3_packed_elems(int32_t cout, int32_t cin, int32_t cout_tile);
 int xm3d_conv3x3_pack_weight(const void* w_ohwi, int32_t cout, int32_t cin, int32_t cout_tile, void* packed, void* stream);
 int64_t xm3d_conv3x3_ws_bytes(int64_t B, int32_t cin);
 int xm3d_conv3x3_nhwc(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,

@@ -108,8 +108,9 @@ def test_conv3x3_rejects_what_it_cannot_run(dev):
 
     x = _nhwc(torch.zeros(1, 64, 8, 16, device=dev, dtype=torch.bfloat16))  # W % 32 != 0
     assert not ops.conv3x3_supported(x, 128)
+    assert not ops.conv3x3_supported(_nhwc(torch.zeros(1, 64, 8, 32, device=dev, dtype=torch.bfloat16)), 64)  # half-empty only tile
     with pytest.raises(TypeError):
-        ops.conv3x3_pack_weight(torch.zeros(96, 64, 3, 3, device=dev))  # cout % 128 != 0
+        ops.conv3x3_pack_weight(torch.zeros(80, 64, 3, 3, device=dev))  # cout % 32 != 0
     x = _nhwc(torch.zeros(1, 64, 8, 32, device=dev, dtype=torch.bfloat16))
     packed, tile = ops.conv3x3_pack_weight(torch.zeros(128, 64, 3, 3, device=dev))
     with pytest.raises(Xm3dError):  # an activation without statistics
@@ -203,7 +204,9 @@ def test_conv3x3_groupnorm_relu_and_projection_bottleneck(dev):
 # at the TRUE spatial size, one view: VAE encoder / decoder ResnetBlocks, UNet ResBlocks at 64^2 / 32^2, projection bottleneck
 PATH_SHAPES = [(128, 128, 512, 512), (128, 256, 256, 256), (256, 256, 256, 256), (256, 512, 128, 128), (512, 512, 128, 128),
                (512, 512, 64, 64), (640, 640, 64, 64), (320, 640, 32, 32), (640, 640, 32, 32), (1280, 1280, 32, 32),
-               (1920, 640, 32, 32), (1280, 640, 32, 32), (960, 640, 32, 32), (128, 128, 128, 128)]
+               (1920, 640, 32, 32), (1280, 640, 32, 32), (960, 640, 32, 32), (128, 128, 128, 128),
+               # UNet level 0 (64^2): cout = 320 = 2.5 tiles of 128, the last one half empty
+               (320, 320, 64, 64), (640, 320, 64, 64), (960, 320, 64, 64)]
 
 
 @pytest.mark.parametrize("cin,cout,H,W", PATH_SHAPES)
@@ -229,3 +232,22 @@ def test_conv3x3_every_shape_of_the_path_matches_torch_fp32(dev, cin, cout, H, W
         o = out.float().view(1, gs, cout // gs, H * W)
         want = torch.stack([o.sum((2, 3)), (o * o).sum((2, 3))], -1).double()
         assert ((st - want).abs() / (want.abs() + 1.0)).max().item() < 1e-4
+
+
+@pytest.mark.parametrize("waves", [4, 8])
+def test_conv3x3_cout_not_a_multiple_of_the_tile(dev, waves):
+    """cout = 320 / 160 / 352: zero-padded last tile, nothing is written past the real channels (the output tensor has exactly cout
+    channels per pixel, so a stray store would land in the next pixel and show up as an error there)"""
+    from xmask3d_amd import ops
+
+    for cin, cout in ((64, 320), (128, 160), (64, 352)):
+        g = torch.Generator().manual_seed(cout + waves)
+        x = _nhwc(torch.randn(2, cin, 16, 32, generator=g).to(dev, torch.bfloat16))
+        w = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev, torch.bfloat16)
+        bias = torch.randn(cout, generator=g).to(dev)
+        res = _nhwc(torch.randn(2, cout, 16, 32, generator=g).to(dev, torch.bfloat16))
+        packed, tile = ops.conv3x3_pack_weight(w)
+        assert tile == 128 and packed.numel() == -(-cout // 128) * 128 * 9 * cin
+        out = ops.conv3x3(x, packed, cout, tile, bias=bias, residual=res, waves=waves)
+        ref = F.conv2d(x.float(), w.float(), bias, padding=1) + res.float()
+        assert out.shape == ref.shape and (out.float() - ref).abs().max().item() < 1e-2 * ref.abs().max().item()

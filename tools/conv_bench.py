@@ -17,7 +17,8 @@ only = sys.argv[3] if len(sys.argv) > 3 else ""
 dev = torch.device("cuda:0")
 SHAPES = [("vae 128@512", 128, 128, 512, 512), ("vae 256@256", 256, 256, 256, 256), ("vae 512@128", 512, 512, 128, 128),
           ("vae 512@64", 512, 512, 64, 64), ("vae 128>256@256", 128, 256, 256, 256), ("vae 256>512@128", 256, 512, 128, 128),
-          ("unet 640@32", 640, 640, 32, 32), ("unet 1280@32", 1280, 1280, 32, 32), ("unet 1920>640@32", 1920, 640, 32, 32)]
+          ("unet 640@32", 640, 640, 32, 32), ("unet 1280@32", 1280, 1280, 32, 32), ("unet 1920>640@32", 1920, 640, 32, 32),
+          ("unet 320@64", 320, 320, 64, 64), ("unet 640>320@64", 640, 320, 64, 64), ("unet 960>320@64", 960, 320, 64, 64)]
 
 
 def timeit(fn, n):

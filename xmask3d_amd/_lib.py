@@ -59,6 +59,7 @@ _SIGS = {
     "xm3d_group_norm_nhwc_apply": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp, ctypes.c_float, c_i32, c_vp, c_vp,
                                                 c_vp, c_vp]),
     "xm3d_conv3x3_cout_tile": (ctypes.c_int, [c_i32]),
+    "xm3d_conv3x3_packed_elems": (ctypes.c_int64, [c_i32, c_i32, c_i32]),
     "xm3d_conv3x3_pack_weight": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_conv3x3_ws_bytes": (ctypes.c_int64, [c_i64, c_i32]),
     "xm3d_conv3x3_nhwc": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_i32, c_i32,

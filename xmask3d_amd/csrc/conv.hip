@@ -294,7 +294,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
     const bool want_stats = a.stats_out != nullptr;
     const int cg_out = a.cg_out;
     const int g_first = want_stats ? (ct * CT) / cg_out : 0;
-    const int g_last = want_stats ? (ct * CT + CT - 1) / cg_out : 0;
+    const int g_last = want_stats ? (min(ct * CT + CT, a.cout) - 1) / cg_out : 0;
     if (want_stats) {
         if (tid < 2 * (g_last - g_first + 1)) sred[tid] = 0.f;
         __syncthreads();
@@ -314,13 +314,16 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
         // row block outer the two halves of a line left L2 separately (WRITE_SIZE 1.22 x the output, profiles/r03_roofline_pmc.txt)
         float gs[MB][4], gq[MB][4];
         float4 bq[MB][4];
+        bool live[MB];  // cout that is no multiple of the tile (UNet: 320 = 2.5 x 128): the row blocks past cout are zero weights, not stored
 #pragma unroll
-        for (int m = 0; m < MB; ++m)
+        for (int m = 0; m < MB; ++m) {
+            live[m] = ct * CT + (wb0 + m) * 32 < a.cout;
 #pragma unroll
             for (int q = 0; q < 4; ++q) {
                 gs[m][q] = gq[m][q] = 0.f;
-                bq[m][q] = bias ? *reinterpret_cast<const float4*>(bias + (wb0 + m) * 32 + 16 * h + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                bq[m][q] = bias && live[m] ? *reinterpret_cast<const float4*>(bias + (wb0 + m) * 32 + 16 * h + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
+        }
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int y = ty * TH + nbase + n, px = tx * CV_TW + l31;
@@ -329,7 +332,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
 #pragma unroll
             for (int m = 0; m < MB; ++m) {
                 rr[m][0] = rr[m][1] = make_uint4(0, 0, 0, 0);
-                if (a.residual) {
+                if (a.residual && live[m]) {
                     const int64_t o = opix + (wb0 + m) * 32 + 16 * h;
                     rr[m][0] = *reinterpret_cast<const uint4*>(a.residual + o);
                     rr[m][1] = *reinterpret_cast<const uint4*>(a.residual + o + 8);
@@ -355,8 +358,10 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
                         gq[m][q] = fmaf(vr, vr, gq[m][q]);
                     }
                 }
-                *reinterpret_cast<cv_bf16x8*>(a.out + o) = pk[0];
-                *reinterpret_cast<cv_bf16x8*>(a.out + o + 8) = pk[1];
+                if (live[m]) {
+                    *reinterpret_cast<cv_bf16x8*>(a.out + o) = pk[0];
+                    *reinterpret_cast<cv_bf16x8*>(a.out + o + 8) = pk[1];
+                }
             }
         }
         if (want_stats) {
@@ -370,7 +375,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
                         s += __shfl_xor(s, off);
                         ss += __shfl_xor(ss, off);
                     }
-                    if (l31 == 0) {
+                    if (l31 == 0 && live[m]) {
                         const int gl = (ct * CT + (wb0 + m) * 32 + 16 * h + 4 * q) / cg_out - g_first;
                         atomicAdd(&sred[2 * gl], s);
                         atomicAdd(&sred[2 * gl + 1], ss);
@@ -390,7 +395,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
 // fragment, as ONE coalesced 16-byte-per-lane load; a wave's k-steps are contiguous (1 KiB each)
 __global__ void k_conv3x3_pack(const __bf16* __restrict__ w, int cout, int cin, int CT, __bf16* __restrict__ out) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // one 16-byte granule of the output
-    const int64_t total = int64_t(cout) * 9 * cin / 8;
+    const int64_t total = int64_t((cout + CT - 1) / CT) * CT * 9 * cin / 8;  // rows past cout (padding of the last tile): zeros
     if (i >= total) return;
     const int nch = cin / CV_KC;
     const int l = int(i & 63);
@@ -406,7 +411,7 @@ __global__ void k_conv3x3_pack(const __bf16* __restrict__ w, int cout, int cin, 
     const int rho = l & 31;  // MFMA row -> channel 16 h + i with rho = (i & 3) + 8 (i >> 2) + 4 h (see the kernel's epilogue)
     const int row = ct * CT + wb * 32 + 16 * ((rho >> 2) & 1) + (rho & 3) + 4 * (rho >> 3);
     const int k = c * CV_KC + ks * 16 + (l >> 5) * 8;
-    reinterpret_cast<uint4*>(out)[i] = *reinterpret_cast<const uint4*>(w + (int64_t(row) * 9 + t) * cin + k);
+    reinterpret_cast<uint4*>(out)[i] = row < cout ? *reinterpret_cast<const uint4*>(w + (int64_t(row) * 9 + t) * cin + k) : make_uint4(0, 0, 0, 0);
 }
 
 // GroupNorm moments -> per-(image, channel) affine y = x * scale + shift, laid out [image][channel / 8][scale 8 | shift 8] so that
@@ -452,14 +457,19 @@ static int dispatch_conv(const ConvArgs& a, int gn_act, bool upsample, hipStream
 
 using namespace xm3d;
 
-extern "C" int xm3d_conv3x3_cout_tile(int cout) { return cout % 256 == 0 ? 256 : (cout % 128 == 0 ? 128 : 0); }
+// 256 / 128 when cout is a multiple; other multiples of 32 (UNet: 320) run on 128-channel tiles with a zero-padded last tile
+extern "C" int xm3d_conv3x3_cout_tile(int cout) { return cout <= 0 ? 0 : (cout % 256 == 0 ? 256 : (cout % 32 == 0 ? 128 : 0)); }
+
+extern "C" int64_t xm3d_conv3x3_packed_elems(int cout, int cin, int cout_tile) {
+    return cout_tile > 0 ? int64_t((cout + cout_tile - 1) / cout_tile) * cout_tile * 9 * cin : 0;
+}
 
 extern "C" int xm3d_conv3x3_pack_weight(const void* w_ohwi, int cout, int cin, int cout_tile, void* packed, void* stream) {
     XM3D_REQUIRE(w_ohwi && packed, "conv3x3_pack_weight: null pointer");
     XM3D_REQUIRE(cin > 0 && cin % CV_KC == 0, "conv3x3_pack_weight: cin %d is not a multiple of %d", cin, CV_KC);
-    XM3D_REQUIRE((cout_tile == 128 || cout_tile == 256) && cout > 0 && cout % cout_tile == 0,
-                 "conv3x3_pack_weight: cout %d / tile %d unsupported", cout, cout_tile);
-    const int64_t total = int64_t(cout) * 9 * cin / 8;
+    XM3D_REQUIRE((cout_tile == 128 || cout_tile == 256) && cout > 0 && cout % 32 == 0, "conv3x3_pack_weight: cout %d / tile %d unsupported", cout,
+                 cout_tile);
+    const int64_t total = xm3d_conv3x3_packed_elems(cout, cin, cout_tile) / 8;
     hipLaunchKernelGGL(k_conv3x3_pack, dim3(unsigned((total + 255) / 256)), dim3(256), 0, as_stream(stream),
                        static_cast<const __bf16*>(w_ohwi), cout, cin, cout_tile, static_cast<__bf16*>(packed));
     XM3D_LAUNCH_CHECK();
@@ -495,8 +505,8 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
     XM3D_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && H % TH == 0 && W % CV_TW == 0,
                  "conv3x3_nhwc: output %dx%d is not a multiple of the %dx%d pixel tile", H, W, TH, CV_TW);
     XM3D_REQUIRE(cin > 0 && cin % CV_KC == 0, "conv3x3_nhwc: cin %d is not a multiple of %d", cin, CV_KC);
-    XM3D_REQUIRE((cout_tile == 128 || cout_tile == 256) && cout > 0 && cout % cout_tile == 0, "conv3x3_nhwc: cout %d / tile %d unsupported",
-                 cout, cout_tile);
+    XM3D_REQUIRE((cout_tile == 128 || cout_tile == 256) && cout > 0 && cout % 32 == 0, "conv3x3_nhwc: cout %d / tile %d unsupported", cout,
+                 cout_tile);
     XM3D_REQUIRE(int64_t(H) * W * (cin > cout ? cin : cout) < (int64_t(1) << 31), "conv3x3_nhwc: image too large for 32-bit offsets");
     XM3D_REQUIRE(bias_bstride == 0 || bias_bstride == cout, "conv3x3_nhwc: bias_bstride must be 0 or cout");
     XM3D_REQUIRE(in_shift_bstride == 0 || in_shift_bstride == cin, "conv3x3_nhwc: in_shift_bstride must be 0 or cin");
@@ -543,7 +553,7 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
     a.cg_out = stats_out ? cout / groups_out : cout;
     a.tiles_x = W / CV_TW;
     a.tiles_y = H / TH;
-    a.nct = cout / cout_tile;
+    a.nct = (cout + cout_tile - 1) / cout_tile;
     const int gn_act = gn ? act : 0;
     if (cout_tile == 256) return waves == 8 ? dispatch_conv<256, 8>(a, gn_act, upsample != 0, s) : dispatch_conv<256, 4>(a, gn_act, upsample != 0, s);
     return waves == 8 ? dispatch_conv<128, 8>(a, gn_act, upsample != 0, s) : dispatch_conv<128, 4>(a, gn_act, upsample != 0, s);

@@ -487,13 +487,14 @@ def gn_stats_of(x, num_groups=32, shift=None):
 
 
 def conv3x3_supported(x, cout, upsample=False):
-    """shapes xm3d_conv3x3_nhwc takes: channels-last bf16, output H % 4 == 0, W % 32 == 0, cin % 64 == 0, cout % 128 == 0"""
+    """shapes xm3d_conv3x3_nhwc takes: channels-last bf16, output H % 4 == 0, W % 32 == 0, cin % 64 == 0, cout % 32 == 0 (cout >= 128:
+    a 64-channel layer would leave half of its only tile empty)"""
     if not (is_nhwc(x) and x.dtype == torch.bfloat16):
         return False
     _, cin, H, W = x.shape
     if upsample:
         H, W = 2 * H, 2 * W
-    return H % 4 == 0 and W % 32 == 0 and cin % 64 == 0 and cout % 128 == 0
+    return H % 4 == 0 and W % 32 == 0 and cin % 64 == 0 and cout % 32 == 0 and cout >= 128
 
 
 def conv3x3_pack_weight(weight):
@@ -503,7 +504,7 @@ def conv3x3_pack_weight(weight):
     if tile == 0 or cin % 64 != 0 or tuple(weight.shape[2:]) != (3, 3):
         raise TypeError(f"conv3x3_pack_weight: unsupported weight shape {tuple(weight.shape)}")
     w = weight.detach().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()  # OHWI
-    packed = torch.empty_like(w)
+    packed = torch.empty(lib().xm3d_conv3x3_packed_elems(cout, cin, tile), dtype=torch.bfloat16, device=w.device)
     check(lib().xm3d_conv3x3_pack_weight(_ptr(w), cout, cin, tile, _ptr(packed), _stream()), "xm3d_conv3x3_pack_weight")
     return packed, tile
 
@@ -585,7 +586,7 @@ def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_grou
     in_shift: (cin,) or (B, cin) f32 added to x in front of the GroupNorm (gn's moments must be those of x + in_shift).
     waves: 0 = the library's choice, 8 / 4 = workgroup geometry (same results)."""
     if not conv3x3_supported(x, cout, upsample):
-        raise TypeError(f"conv3x3: unsupported input {tuple(x.shape)} {x.dtype} (channels-last bf16, H % 8, W % 32, cin % 64, cout % 128)")
+        raise TypeError(f"conv3x3: unsupported input {tuple(x.shape)} {x.dtype} (channels-last bf16, H % 4, W % 32, cin % 64, cout % 32)")
     B, cin, H, W = x.shape
     if upsample:
         H, W = 2 * H, 2 * W
