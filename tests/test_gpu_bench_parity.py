@@ -196,7 +196,7 @@ def test_other_benchmark_configs_match_oracle_per_stage(dev, name):
     off = batch["point_offsets"]
     n_test = len(cfg.category_split["base_category"]) + len(cfg.category_split["novel_category"])
     assert out["pred_logits"].shape[-1] == n_test + 1
-    for v in (1, 4):
+    for v in (4,):  # one view per config: the CPU oracle forward is 35 s of host time per view
         ref = oracle_view(cpu, scene, v, (name, v))
         rep = stage_report(out, v, slice(off[v], off[v + 1]), ref)
         print(f"[parity {name} fp32 view {v}] " + " ".join(f"{k}={x:.3e}" for k, x in rep.items()))
