@@ -260,13 +260,17 @@ int xm3d_conv3x3_default_waves(int32_t H, int32_t W, int32_t cin, int32_t cout);
  *                                  be used with (GEGLU interleaves value and gate rows)
  *   xm3d_gemm_bf16               : x (M, K) bf16 with row stride ldx; out / residual (M, N_out) with row strides ldo / ldr (elements);
  *                                  bias (N) f32 or NULL; residual may be NULL.
- *   Constraints: K % 64 == 0, N % 32 == 0, row strides multiples of 8 elements, 16-byte aligned tensors; any M > 0.
+ *                                  col_tile: 256 or 128 - the packed image serves both (an image packed for 256 may be run with 128);
+ *                                  waves: 0 (choose: xm3d_gemm_default_waves), 8 (256-row workgroups) or 4 (128-row workgroups, col_tile 128
+ *                                  only: small M); results do not depend on either.
+ *   Constraints: K % 64 == 0, N % 32 == 0, row strides multiples of 8 elements, M * ldx < 2^31, 16-byte aligned tensors; any M > 0.
  *   Launched on `stream`, no host synchronisation. */
 int xm3d_gemm_col_tile(int32_t n_rows);
 int64_t xm3d_gemm_packed_elems(int32_t n_rows, int32_t K, int32_t col_tile);
 int xm3d_gemm_pack_weight(const void* w, int32_t w_is_f32, int32_t N, int32_t K, int32_t act, int32_t col_tile, void* packed, void* stream);
+int xm3d_gemm_default_waves(int64_t M, int32_t N, int32_t col_tile);
 int xm3d_gemm_bf16(const void* x, int64_t M, int32_t K, int64_t ldx, const void* wpacked, int32_t N, int32_t col_tile, const float* bias, int32_t act,
-                   const void* residual, int64_t ldr, void* out, int64_t ldo, void* stream);
+                   const void* residual, int64_t ldr, void* out, int64_t ldo, int32_t waves, void* stream);
 /* GroupNorm moments alone, in the layout the calls above take: stats (B*G*2) f64 <- (sum, sum of squares) of x (+ shift) per
  * (sample, group); x (B, H*W, C) channels-last, dtype 0 = f32 / 1 = bf16; stats is zeroed here. */
 int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,

@@ -66,8 +66,13 @@ def test_gemm_matches_reference(M, K, N, act, has_bias, has_res):
     nout = N // 2 if act == "geglu" else N
     res = torch.randn(M, nout, generator=g).to(dev, torch.bfloat16) if has_res else None
     packed, tile = ops.gemm_pack_weight(w, act)
+    ref = _ref(x, w, bias, act, res)
     out = ops.gemm(x, packed, N, tile, bias=bias, act=act, residual=res)
-    _check(out, _ref(x, w, bias, act, res))
+    _check(out, ref)
+    # both workgroup geometries give the same result (same products, same summation order per output)
+    o8, o4 = (ops.gemm(x, packed, N, tile, bias=bias, act=act, residual=res, waves=w_) for w_ in (8, 4))
+    _check(o8, ref)
+    assert torch.equal(o8, o4)
 
 
 def test_gemm_bf16_weight_strided_rows_and_batch_dims():

@@ -68,7 +68,8 @@ _SIGS = {
     "xm3d_gemm_col_tile": (ctypes.c_int, [c_i32]),
     "xm3d_gemm_packed_elems": (ctypes.c_int64, [c_i32, c_i32, c_i32]),
     "xm3d_gemm_pack_weight": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
-    "xm3d_gemm_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_vp]),
+    "xm3d_gemm_default_waves": (ctypes.c_int, [c_i64, c_i32, c_i32]),
+    "xm3d_gemm_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
     "xm3d_group_norm_nhwc_stats": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_bias_residual_nhwc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "xm3d_attn_mask_bias": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),

@@ -37,10 +37,7 @@ typedef __bf16 gm_bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned gm_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int GM_MT = 256;               // token rows per workgroup
-constexpr int GM_KC = 64;                // K per chunk
-constexpr int GM_PSTR = 144;             // bytes per staged row: 64 bf16 + 16 pad
-constexpr int GM_ASZ = GM_MT * GM_PSTR;  // bytes per LDS buffer
-constexpr int GM_LDS = 2 * GM_ASZ;
+constexpr int GM_KC = 64;                // K granularity (chunks are 64 or, when K allows, 128 channels: template KC)
 constexpr int GM_D = 8;                  // weight ring depth in k-steps (= two chunks)
 
 enum { GM_ACT_NONE = 0, GM_ACT_GELU = 1, GM_ACT_QUICK_GELU = 2, GM_ACT_GEGLU = 3 };
@@ -66,16 +63,27 @@ __device__ __forceinline__ float gm_gelu(float x) {
     return 0.5f * x * (1.f + copysignf(e, x));
 }
 
-template <int CT, int ACT>
-__global__ __launch_bounds__(512) void k_gemm(const GemmArgs a) {
+// NW = 8: 512 threads, 256 token rows (one workgroup per CU).  NW = 4 (CT = 128 only): 256 threads, 128 token rows, a wave = one
+// 32-column block x all 128 rows; two to three workgroups per CU - the geometry for small M (M = 5 k rows x 256-row tiles leaves
+// the chip two thirds empty) and for overlapping one workgroup's prologue / epilogue with another's K loop
+template <int CT, int ACT, int KC, int NW>
+__global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
+    static_assert(NW == 8 || (NW == 4 && CT == 128), "geometries");
+    constexpr int MT = NW * 32;            // token rows per workgroup
+    constexpr int NTH = NW * 64;
     constexpr int NT = CT == 256 ? 8 : 4;  // 32-token tiles per wave
     constexpr int NG = NT / 4;             // groups of 4 MFMAs per k-step
+    constexpr int KS = KC / 16;            // k-steps per chunk = 16-byte pieces per thread and chunk (4 or 8)
+    constexpr int PSTR = KC * 2 + 16;      // bytes per staged row (144 / 272: the 32-row fragment reads stay bank-conflict free)
+    constexpr int ASZ = MT * PSTR;         // bytes per LDS buffer
+    constexpr int RPR = NTH / (KC / 8);    // rows staged per round
+    constexpr int D = (CT == 256 && KC == 128) ? 4 : GM_D;  // weight ring depth in k-steps (register budget: 128 accumulators + 32 pieces there)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wb = CT == 256 ? wave : wave >> 1;        // 32-column row block of this wave inside the tile
-    const int nbase = CT == 128 ? 4 * (wave & 1) : 0;   // first 32-token tile of this wave
+    const int wb = (CT == 256 || NW == 4) ? wave : wave >> 1;         // 32-column row block of this wave inside the tile
+    const int nbase = (CT == 128 && NW == 8) ? 4 * (wave & 1) : 0;    // first 32-token tile of this wave
     const int l31 = lane & 31, h = lane >> 5;
 
     int bid;  // XCD-aware order (speed only): an XCD's L2 sees a contiguous run of tiles; column tiles of one row tile are adjacent
@@ -84,8 +92,8 @@ __global__ __launch_bounds__(512) void k_gemm(const GemmArgs a) {
         bid = (xcd < r ? xcd * (qd + 1) : r * (qd + 1) + (xcd - r) * qd) + (i >> 3);
     }
     const int ct = bid % a.nct, mt = bid / a.nct;
-    const int row0 = mt * GM_MT, M = a.M;
-    const int nch = a.K / GM_KC, nk = nch * 4;
+    const int row0 = mt * MT, M = a.M;
+    const int nch = a.K / KC, nk = nch * KS;
     // N that is not a multiple of the column tile (UNet: 320, 960 with CT = 128): the row blocks past N in the last tile belong to
     // waves that only stage tokens - no weight stream, no fragment reads, no MFMAs (their SIMD's other wave runs alone)
     const int gblk = ct * (CT / 32) + wb;  // global 32-row block of W
@@ -93,29 +101,28 @@ __global__ __launch_bounds__(512) void k_gemm(const GemmArgs a) {
 
     // ---- weight stream of this wave: 1 KiB (64 lanes x 16 bytes = one A fragment) per k-step, contiguous
     const char* const wstream = reinterpret_cast<const char*>(a.wp) + (int64_t(ct) * (CT / 32) + wb) * nk * 1024 + lane * 16;
-    gm_bf16x8 wr[GM_D];
+    gm_bf16x8 wr[D];
 #pragma unroll
-    for (int i = 0; i < GM_D; ++i) wr[i] = *reinterpret_cast<const gm_bf16x8*>(wstream + int64_t(i < nk ? i : nk - 1) * 1024);
+    for (int i = 0; i < D; ++i) wr[i] = *reinterpret_cast<const gm_bf16x8*>(wstream + int64_t(i < nk ? i : nk - 1) * 1024);
 
-    // ---- token staging: thread owns the 16-byte piece (row prow + 64 r, channels 8 kc .. 8 kc + 7) of every chunk, r = 0 .. 3.
-    // Rows past M read row M - 1 (their results are never stored)
-    const int kc = tid & 7, prow = tid >> 3;
-    const __bf16* asrc[4];
+    // ---- token staging: thread owns the 16-byte piece (row prow + RPR r, channels 8 kc .. 8 kc + 7) of every chunk, r = 0 .. KS - 1.
+    // Rows past M read row M - 1 (their results are never stored).  ONE register per piece: piece r of chunk c + 1 is written to LDS
+    // in k-step r of chunk c and the register is re-requested right there for chunk c + 2 - every load has a whole chunk to land
+    const int kc = tid % (KC / 8), prow = tid / (KC / 8);
+    unsigned aoff[KS];  // element offsets (32 bit: the host checks M * ldx < 2^31)
 #pragma unroll
-    for (int r = 0; r < 4; ++r) {
-        const int row = row0 + prow + 64 * r;
-        asrc[r] = a.x + int64_t(row < M ? row : M - 1) * a.ldx + kc * 8;
+    for (int r = 0; r < KS; ++r) {
+        const int row = row0 + prow + RPR * r;
+        aoff[r] = unsigned(row < M ? row : M - 1) * unsigned(a.ldx) + kc * 8;
     }
-    char* const a_wr = smem + prow * GM_PSTR + kc * 16;  // + r * 64 * GM_PSTR + buffer
-    gm_u32x4 raw[2][4];
-    auto a_load = [&](int set, int c) __attribute__((always_inline)) {
-        const int c0 = (c < nch ? c : nch - 1) * GM_KC;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) raw[set][r] = *reinterpret_cast<const gm_u32x4*>(asrc[r] + c0);
+    char* const a_wr = smem + prow * PSTR + kc * 16;  // + r * RPR * PSTR + buffer
+    gm_u32x4 raw[KS];
+    auto a_load = [&](int r, int c) __attribute__((always_inline)) {
+        raw[r] = *reinterpret_cast<const gm_u32x4*>(a.x + aoff[r] + (c < nch ? c : nch - 1) * KC);
     };
 
     // tokens as B operand: row (nbase + n) * 32 + l31 of the tile, 16-byte granule 2 ks + h
-    const char* const xbase = smem + (nbase * 32 + l31) * GM_PSTR + h * 16;
+    const char* const xbase = smem + (nbase * 32 + l31) * PSTR + h * 16;
 
     gm_f32x16 acc[NT];
 #pragma unroll
@@ -124,43 +131,48 @@ __global__ __launch_bounds__(512) void k_gemm(const GemmArgs a) {
         for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 
     // ---- prologue: chunk 0 into buffer 0, chunk 1 requested
-    a_load(0, 0);
 #pragma unroll
-    for (int r = 0; r < 4; ++r) *reinterpret_cast<gm_u32x4*>(a_wr + r * 64 * GM_PSTR) = raw[0][r];
-    a_load(1, 1);
+    for (int r = 0; r < KS; ++r) a_load(r, 0);
+#pragma unroll
+    for (int r = 0; r < KS; ++r) *reinterpret_cast<gm_u32x4*>(a_wr + r * RPR * PSTR) = raw[r];
+#pragma unroll
+    for (int r = 0; r < KS; ++r) a_load(r, 1);
     __syncthreads();
 
-    // chunk c (parity P = c & 1): MFMAs on LDS buffer P; the pieces of chunk c + 1 (registers raw[1 - P], requested during chunk
-    // c - 1) go to buffer 1 - P, one per k-step; the pieces of chunk c + 2 are requested into raw[P]
+    // chunk c (parity P = c & 1): MFMAs on LDS buffer P; in k-step ks piece ks of chunk c + 1 goes to buffer 1 - P and is re-requested
+    // for chunk c + 2; ring slot of k-step ks = (P KS + ks) mod D
     auto chunk = [&](int c, auto par_tag, auto act_tag) __attribute__((always_inline)) {
         constexpr int P = decltype(par_tag)::value;
         constexpr bool ACTV = decltype(act_tag)::value;  // a wave past N only stages (one branch per chunk, straight-line bodies)
-        const char* const xl = xbase + P * GM_ASZ;
-        char* const anext = a_wr + (1 - P) * GM_ASZ;
+        const char* const xl = xbase + P * ASZ;
+        char* const anext = a_wr + (1 - P) * ASZ;
         gm_bf16x8 xf[2][4];
-        constexpr int XS = 4 * NG;  // x-sets (4 token tiles each) per chunk
+        constexpr int XS = KS * NG;  // x-sets (4 token tiles each) per chunk
         auto x_load = [&](int xs, int s) __attribute__((always_inline)) {
             const int ks = xs / NG, half = xs % NG;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) xf[s][n] = *reinterpret_cast<const gm_bf16x8*>(xl + (half * 4 + n) * 32 * GM_PSTR + ks * 32);
+            for (int n = 0; n < 4; ++n) xf[s][n] = *reinterpret_cast<const gm_bf16x8*>(xl + (half * 4 + n) * 32 * PSTR + ks * 32);
         };
         if (ACTV) x_load(0, 0);
-        a_load(P, c + 2);
 #pragma unroll
         for (int g = 0; g < XS; ++g) {
             const int ks = g / NG, half = g % NG;
+            const int slot = (P * KS + ks) % D;
             __builtin_amdgcn_sched_barrier(0);
             if (ACTV && g + 1 < XS) x_load(g + 1, (g + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
-            if (half == 0) *reinterpret_cast<gm_u32x4*>(anext + ks * 64 * GM_PSTR) = raw[1 - P][ks];
+            if (half == 0) {
+                *reinterpret_cast<gm_u32x4*>(anext + ks * RPR * PSTR) = raw[ks];
+                a_load(ks, c + 2);
+            }
             if (ACTV) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n)
-                    acc[half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[P * 4 + ks], xf[g & 1][n], acc[half * 4 + n], 0, 0, 0);
-                if (half == NG - 1) {  // the ring slot is free: request the fragment of k-step + 8
+                    acc[half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[slot], xf[g & 1][n], acc[half * 4 + n], 0, 0, 0);
+                if (half == NG - 1) {  // the ring slot is free: request the fragment of k-step + D
                     __builtin_amdgcn_sched_barrier(0);
-                    const int jn = c * 4 + ks + GM_D;
-                    wr[P * 4 + ks] = *reinterpret_cast<const gm_bf16x8*>(wstream + int64_t(jn < nk ? jn : nk - 1) * 1024);
+                    const int jn = c * KS + ks + D;
+                    wr[slot] = *reinterpret_cast<const gm_bf16x8*>(wstream + int64_t(jn < nk ? jn : nk - 1) * 1024);
                 }
             }
         }
@@ -292,26 +304,38 @@ __global__ void k_gemm_pack(const T* __restrict__ w, int N, int K, int nblk, int
     reinterpret_cast<gm_bf16x8*>(out)[i] = o;
 }
 
-template <int CT, int ACT>
-static int launch_gemm(const GemmArgs& a, hipStream_t s) {
+template <int CT, int ACT, int KC, int NW>
+static int launch_gemm_kc(const GemmArgs& a, hipStream_t s) {
+    constexpr int MT = NW * 32;
+    constexpr int LDS = 2 * MT * (KC * 2 + 16);
     static bool configured = false;
     if (!configured) {
-        XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<CT, ACT>), hipFuncAttributeMaxDynamicSharedMemorySize, GM_LDS));
+        XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<CT, ACT, KC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
         configured = true;
     }
-    const int grid = ((a.M + GM_MT - 1) / GM_MT) * a.nct;
-    hipLaunchKernelGGL((k_gemm<CT, ACT>), dim3(grid), dim3(512), GM_LDS, s, a);
+    const int grid = ((a.M + MT - 1) / MT) * a.nct;
+    hipLaunchKernelGGL((k_gemm<CT, ACT, KC, NW>), dim3(grid), dim3(NW * 64), LDS, s, a);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
 
+// 128-channel chunks (one barrier per 8 k-steps) whenever K allows; K = 320 and other odd multiples of 64 run 64-channel chunks.
+// waves: 8 / 4 (4: CT = 128 only)
+template <int CT, int ACT>
+static int launch_gemm(const GemmArgs& a, int waves, hipStream_t s) {
+    if constexpr (CT == 128) {
+        if (waves == 4) return a.K % 128 == 0 ? launch_gemm_kc<CT, ACT, 128, 4>(a, s) : launch_gemm_kc<CT, ACT, 64, 4>(a, s);
+    }
+    return a.K % 128 == 0 ? launch_gemm_kc<CT, ACT, 128, 8>(a, s) : launch_gemm_kc<CT, ACT, 64, 8>(a, s);
+}
+
 template <int CT>
-static int dispatch_gemm(const GemmArgs& a, int act, hipStream_t s) {
+static int dispatch_gemm(const GemmArgs& a, int act, int waves, hipStream_t s) {
     switch (act) {
-        case GM_ACT_NONE: return launch_gemm<CT, GM_ACT_NONE>(a, s);
-        case GM_ACT_GELU: return launch_gemm<CT, GM_ACT_GELU>(a, s);
-        case GM_ACT_QUICK_GELU: return launch_gemm<CT, GM_ACT_QUICK_GELU>(a, s);
-        default: return launch_gemm<CT, GM_ACT_GEGLU>(a, s);
+        case GM_ACT_NONE: return launch_gemm<CT, GM_ACT_NONE>(a, waves, s);
+        case GM_ACT_GELU: return launch_gemm<CT, GM_ACT_GELU>(a, waves, s);
+        case GM_ACT_QUICK_GELU: return launch_gemm<CT, GM_ACT_QUICK_GELU>(a, waves, s);
+        default: return launch_gemm<CT, GM_ACT_GEGLU>(a, waves, s);
     }
 }
 
@@ -321,6 +345,9 @@ using namespace xm3d;
 
 // column tile for N rows of W: 256 when that wastes nothing (or N is large), else 128; the packed image is padded to whole tiles
 extern "C" int xm3d_gemm_col_tile(int n_rows) { return n_rows % 256 == 0 ? 256 : 128; }
+
+// the packed image does not depend on the column tile (32-row blocks, padded to a multiple of 256 rows for either): a weight packed
+// for tile 256 may be run with tile 128 (the 4-wave geometry needs 128)
 
 extern "C" int64_t xm3d_gemm_packed_elems(int n_rows, int K, int col_tile) {
     const int64_t npad = (int64_t(n_rows) + col_tile - 1) / col_tile * col_tile;
@@ -346,10 +373,18 @@ extern "C" int xm3d_gemm_pack_weight(const void* w, int w_is_f32, int N, int K, 
     return XM3D_OK;
 }
 
+// workgroup geometry when the caller does not choose (waves = 0): 128-row, 4-wave workgroups (column tile 128 only) when the 256-row
+// grid would not give every CU two workgroups' worth of tiles
+extern "C" int xm3d_gemm_default_waves(int64_t M, int N, int col_tile) {
+    if (col_tile != 128) return 8;
+    const int64_t grid8 = ((M + 255) / 256) * ((N + col_tile - 1) / col_tile);
+    return grid8 < 512 ? 4 : 8;
+}
+
 extern "C" int xm3d_gemm_bf16(const void* x, int64_t M, int K, int64_t ldx, const void* wpacked, int N, int col_tile, const float* bias, int act,
-                              const void* residual, int64_t ldr, void* out, int64_t ldo, void* stream) {
+                              const void* residual, int64_t ldr, void* out, int64_t ldo, int waves, void* stream) {
     XM3D_REQUIRE(x && wpacked && out, "gemm_bf16: null pointer");
-    XM3D_REQUIRE(M > 0 && M < (int64_t(1) << 31) - GM_MT, "gemm_bf16: M out of range");
+    XM3D_REQUIRE(M > 0 && M < (int64_t(1) << 31) - GM_MT && M * ldx < (int64_t(1) << 31), "gemm_bf16: M (x ldx) out of range (32-bit offsets)");
     XM3D_REQUIRE(K > 0 && K % GM_KC == 0, "gemm_bf16: K %d is not a multiple of %d", K, GM_KC);
     XM3D_REQUIRE(col_tile == 128 || col_tile == 256, "gemm_bf16: column tile %d unsupported", col_tile);
     XM3D_REQUIRE(N > 0 && N % 32 == 0, "gemm_bf16: N %d is not a multiple of 32", N);
@@ -370,7 +405,8 @@ extern "C" int xm3d_gemm_bf16(const void* x, int64_t M, int K, int64_t ldx, cons
     a.M = int(M), a.K = K, a.N = N;
     a.ldx = int(ldx), a.ldr = int(ldr), a.ldo = int(ldo);
     a.nct = (N + col_tile - 1) / col_tile;
-    const int64_t grid = ((M + GM_MT - 1) / GM_MT) * a.nct;
-    XM3D_REQUIRE(grid < (int64_t(1) << 31), "gemm_bf16: grid too large");
-    return col_tile == 256 ? dispatch_gemm<256>(a, act, as_stream(stream)) : dispatch_gemm<128>(a, act, as_stream(stream));
+    XM3D_REQUIRE(((M + 127) / 128) * a.nct < (int64_t(1) << 31), "gemm_bf16: grid too large");
+    XM3D_REQUIRE(waves == 0 || waves == 8 || (waves == 4 && col_tile == 128), "gemm_bf16: waves must be 0 (choose), 8, or 4 with column tile 128");
+    if (waves == 0) waves = xm3d_gemm_default_waves(M, N, col_tile);
+    return col_tile == 256 ? dispatch_gemm<256>(a, act, waves, as_stream(stream)) : dispatch_gemm<128>(a, act, waves, as_stream(stream));
 }

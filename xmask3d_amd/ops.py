@@ -550,9 +550,10 @@ def gemm_pack_weight(weight, act=None):
     return packed, tile
 
 
-def gemm(x, packed, n_rows, tile, bias=None, act=None, residual=None):
+def gemm(x, packed, n_rows, tile, bias=None, act=None, residual=None, waves=0):
     """out = act(x @ W^T + bias) (+ residual) over the last dimension of x; "geglu": out = (x Wv^T + bv) * GELU(x Wg^T + bg) with
-    W = [Wv; Wg] (n_rows = 2 * out features).  x (..., K) bf16, bias f32 (n_rows) or None, residual like the output or None."""
+    W = [Wv; Wg] (n_rows = 2 * out features).  x (..., K) bf16, bias f32 (n_rows) or None, residual like the output or None.
+    waves: 0 = the library's choice of workgroup geometry, 8 / 4 (same results)."""
     k = x.shape[-1]
     rows = _rows_of(x) if x.is_cuda and x.dtype == torch.bfloat16 else None
     if rows is None or k % 64 != 0:
@@ -569,7 +570,9 @@ def gemm(x, packed, n_rows, tile, bias=None, act=None, residual=None):
         ldr = rr[1]
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != n_rows):
         raise TypeError("gemm: bias must be a contiguous f32 (n_rows,) tensor")
-    check(lib().xm3d_gemm_bf16(_ptr(x), m, k, ldx, _ptr(packed), n_rows, tile, _ptr(bias), a, _ptr(residual), ldr, _ptr(out), nout, _stream()),
+    if tile == 256 and (waves == 4 or (waves == 0 and ((m + 255) // 256) * (n_rows // 256) < 200)):
+        tile = 128  # fewer 256 x 256 tiles than CUs: 128-row, 4-wave workgroups on 128-column tiles (the packed image serves both)
+    check(lib().xm3d_gemm_bf16(_ptr(x), m, k, ldx, _ptr(packed), n_rows, tile, _ptr(bias), a, _ptr(residual), ldr, _ptr(out), nout, int(waves), _stream()),
           "xm3d_gemm_bf16")
     return out
 

@@ -104,15 +104,16 @@ _GEMM_LIBRARY = os.environ.get("XM3D_GEMM", "hip") == "library"  # A/B switch: e
 def gemm_ok(x, n_rows, act=None, fused_residual=False):
     """bf16 inference rows on a (K, N) where k_gemm beats the library chain it replaces (tools/gemm_bench.py on MI355X, 20 views,
     profiles/r03_gemm_bench.log): the HBM-bound projections of the 64^2 / 32^2 UNet levels, the VAE AttnBlock and the cross
-    attention's context projections (K <= 768), plus K = 1280 when a residual add rides in the epilogue.  The MFMA-bound ones
-    (K >= 1280, the 640 / 1280-wide GEGLU, mask-CLIP) stay on hipBLASLt, which is 1.1 - 2 x faster there."""
+    attention's context projections (K <= 768), plus the feed-forward output projections of the 64^2 / 32^2 levels, where the residual
+    add rides in the epilogue (x1.03 - 1.11).  The MFMA-bound ones (the 16^2 level, the 640 / 1280-wide GEGLU, mask-CLIP) stay on
+    hipBLASLt, which is 1.0 - 1.3 x faster there."""
     if _GEMM_LIBRARY or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.bfloat16:
         return False
     k = x.shape[-1]
     if act == "geglu":
         wins = k <= 320
     else:
-        wins = k <= 768 or (fused_residual and k <= 1280 and n_rows <= 320)
+        wins = k <= 768 or (fused_residual and k <= 2560 and n_rows <= 640)
     return wins and ops.gemm_supported(x, n_rows, k)
 
 
