@@ -122,11 +122,21 @@ BF16 = {"pred_3d": 5e-5, "pred_masks": 8e-2, "mask_embed": 1e-1, "mask_embed_cli
 
 
 # (fp32 eager batch 1, the reference's own configuration: tests/test_gpu_model.py::test_eval_forward_matches_cpu_oracle, same bounds)
-@pytest.mark.parametrize("mode", ["fp32_graph_nhwc", "bf16_bench"])
-def test_configuration_matches_oracle_per_stage(dev, setup, mode):
+# fp32 with the OPT-IN split-operand convolutions (XM3D_CONV_F32=hip, ops.conv3x3_f32: 2e-5 per layer): the ~60 convolutions in
+# sequence bring the stages to ~1e-3 (measured: pred_masks 1.0e-3, mask_embed 1.5e-3, pred_logits 8e-4, fused 1.2e-3, per-point
+# logits 6e-4).  Inside north_star's 1e-3 on the per-point logits on these views, but without the 6x margin of the exact-f32
+# convolutions - the reason it is not the default of the fp32 configuration.
+FP32_SPLIT = {"pred_3d": 5e-5, "pred_masks": 4e-3, "mask_embed": 5e-3, "mask_embed_clip": 1e-4, "pred_logits_abs": 3e-3,
+              "fused_rel": 4e-3, "point_logits_abs": 2e-3}
+
+
+@pytest.mark.parametrize("mode", ["fp32_graph_nhwc", "bf16_bench", "fp32_split_conv"])
+def test_configuration_matches_oracle_per_stage(dev, setup, mode, monkeypatch):
     from xmask3d_amd import pipeline
 
     cfg, cpu, scenes = setup
+    if mode == "fp32_split_conv":
+        monkeypatch.setenv("XM3D_CONV_F32", "hip")
     dtype = torch.bfloat16 if mode == "bf16_bench" else torch.float32
     model = pipeline.make_inference_model(cpu, dev, dtype, channels_last=True, graphs=True)
     # bf16: 2 scenes x 5 views in ONE forward (batch 10), as bench does; fp32: one scene per forward, like bench's fp32 leg
@@ -135,7 +145,7 @@ def test_configuration_matches_oracle_per_stage(dev, setup, mode):
     vox = pipeline.default_voxelizer(cfg.voxel_size, dev)
     batch, out = _forward_group(model, sds, vox)
     off = batch["point_offsets"]
-    bounds = BF16 if mode == "bf16_bench" else FP32
+    bounds = BF16 if mode == "bf16_bench" else (FP32_SPLIT if mode == "fp32_split_conv" else FP32)
     worst = {}
     for (si, v) in (((0, 0), (0, 3), (1, 2)) if mode == "bf16_bench" else ((0, 0), (0, 3))):   # through the oracle (5 s each)
         b = si * 5 + v
@@ -151,8 +161,8 @@ def test_configuration_matches_oracle_per_stage(dev, setup, mode):
     # 0.5-threshold flips under the bf16 budget: with random weights many mask logits sit near the threshold; measured
     # 95.0-98.5 % per view across runs, with 100 % of the per-point LABELS unchanged (a flipped point moves between masks of
     # the same class)
-    assert worst["ownership_agree"] > (0.92 if mode == "bf16_bench" else 0.995)
-    assert worst["point_label_agree"] > (0.97 if mode == "bf16_bench" else 0.9995)
+    assert worst["ownership_agree"] > (0.92 if mode == "bf16_bench" else (0.99 if mode == "fp32_split_conv" else 0.995))
+    assert worst["point_label_agree"] > (0.97 if mode == "bf16_bench" else (0.999 if mode == "fp32_split_conv" else 0.9995))
 
 
 def test_bench_configuration_votes_match_fp32_reference_path(dev, setup):

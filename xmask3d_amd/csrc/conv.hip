@@ -92,8 +92,10 @@ struct ConvGeom {
 // MODE 0: x is the operand as it stands (plain convolution); MODE 2: operand = SiLU(GroupNorm(x)); MODE 1: ReLU(GroupNorm(x)) (the
 // 3x3 convolution of detectron2's GroupNorm BottleneckBlock in the projection backbone, backbone/feature_extractor.py:20-60).
 // UPS: x has half the resolution, the operand is its nearest-neighbour 2x upsampling (ldm's Upsample -> conv).
-template <int CT, int MODE, bool UPS, int NW>
-__global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
+// F32OUT (plain convolutions only): `out` and `residual` are f32 - the accumulating form used by the f32-accurate convolution
+// (three bf16 passes over split operands, xm3d_conv3x3_nhwc_f32acc)
+template <int CT, int MODE, bool UPS, int NW, bool F32OUT>
+__device__ __forceinline__ void conv3x3_body(const ConvArgs& a) {
     using G = ConvGeom<CT, NW>;
     constexpr int TH = G::TH, HPIX = G::HPIX, ASZ = G::ASZ, PR = G::PR, ROUNDS = G::ROUNDS, MB = G::MB, NT = G::NT, NG = G::NG, D = G::D;
     constexpr int NGRP = 36 * NG;          // groups per chunk
@@ -324,6 +326,29 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
                 bq[m][q] = bias && live[m] ? *reinterpret_cast<const float4*>(bias + (wb0 + m) * 32 + 16 * h + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
             }
         }
+        if constexpr (F32OUT) {
+            float* const outf = reinterpret_cast<float*>(a.out);
+            const float* const resf = reinterpret_cast<const float*>(a.residual);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int y = ty * TH + nbase + n, px = tx * CV_TW + l31;
+                const int64_t opix = ((int64_t(b) * H + y) * W + px) * a.cout + ct * CT;
+#pragma unroll
+                for (int m = 0; m < MB; ++m) {
+                    if (!live[m]) continue;
+                    const int64_t o = opix + (wb0 + m) * 32 + 16 * h;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float4 r = resf ? *reinterpret_cast<const float4*>(resf + o + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+                        r.x += acc[m][n][4 * q] + bq[m][q].x, r.y += acc[m][n][4 * q + 1] + bq[m][q].y;
+                        r.z += acc[m][n][4 * q + 2] + bq[m][q].z, r.w += acc[m][n][4 * q + 3] + bq[m][q].w;
+                        *reinterpret_cast<float4*>(outf + o + 4 * q) = r;
+                        gs[m][q] += (r.x + r.y) + (r.z + r.w);
+                        gq[m][q] = fmaf(r.x, r.x, fmaf(r.y, r.y, fmaf(r.z, r.z, fmaf(r.w, r.w, gq[m][q]))));
+                    }
+                }
+            }
+        } else
 #pragma unroll
         for (int n = 0; n < NT; ++n) {
             const int y = ty * TH + nbase + n, px = tx * CV_TW + l31;
@@ -390,6 +415,47 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
     }
 }
 
+template <int CT, int MODE, bool UPS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
+    conv3x3_body<CT, MODE, UPS, NW, false>(a);
+}
+
+template <int CT, bool UPS, int NW>
+__global__ __launch_bounds__(NW * 64, 2) void k_conv3x3_f32acc(const ConvArgs a) {
+    conv3x3_body<CT, 0, UPS, NW, true>(a);
+}
+
+// f32 (B, H*W, C) -> bf16 hi / lo with x = hi + lo (+ <= 2^-17 |x|), optionally through y = act(x * scale + shift) with the
+// per-(image, channel) GroupNorm affine of k_gn_affine: the operand split of the f32-accurate convolution.  One thread = 8 channels.
+__global__ void k_split_nhwc(const float* __restrict__ x, const float* __restrict__ affine, int act, int64_t n8, int C, int64_t hw,
+                             __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n8) return;
+    const int c8 = C / 8;
+    const int c = int(i % c8);
+    const int64_t b = i / c8 / hw;
+    const float4 v0 = *reinterpret_cast<const float4*>(x + i * 8), v1 = *reinterpret_cast<const float4*>(x + i * 8 + 4);
+    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+    if (affine) {
+        const float* t = affine + (b * C + c * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            float y = fmaf(v[j], t[j], t[8 + j]);
+            if (act == 1) y = y / (1.f + expf(-y));
+            else if (act == 2) y = fmaxf(y, 0.f);
+            v[j] = y;
+        }
+    }
+    cv_bf16x8 h8, l8;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        h8[j] = (__bf16)v[j];
+        l8[j] = (__bf16)(v[j] - float(h8[j]));
+    }
+    *reinterpret_cast<cv_bf16x8*>(hi + i * 8) = h8;
+    *reinterpret_cast<cv_bf16x8*>(lo + i * 8) = l8;
+}
+
 // OHWI (cout, 9, cin) bf16 -> fragment-ordered weight streams [cout tile][32-row block][chunk][tap][k-step][lane][8]: lane l of
 // the wave that owns a row block loads, per k-step, the 8 channels 16 ks + 8 (l >> 5) .. + 7 of row (l & 31) = its MFMA A
 // fragment, as ONE coalesced 16-byte-per-lane load; a wave's k-steps are contiguous (1 KiB each)
@@ -442,6 +508,20 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     }
     const int grid = a.B * a.tiles_y * a.tiles_x * a.nct;
     hipLaunchKernelGGL((k_conv3x3<CT, MODE, UPS, NW>), dim3(grid), dim3(G::NTH), G::LDS, s, a);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+template <int CT, bool UPS, int NW>
+static int launch_conv_f32acc(const ConvArgs& a, hipStream_t s) {
+    using G = ConvGeom<CT, NW>;
+    static bool configured = false;
+    if (!configured) {
+        XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_f32acc<CT, UPS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        configured = true;
+    }
+    const int grid = a.B * a.tiles_y * a.tiles_x * a.nct;
+    hipLaunchKernelGGL((k_conv3x3_f32acc<CT, UPS, NW>), dim3(grid), dim3(G::NTH), G::LDS, s, a);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
@@ -557,4 +637,77 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
     const int gn_act = gn ? act : 0;
     if (cout_tile == 256) return waves == 8 ? dispatch_conv<256, 8>(a, gn_act, upsample != 0, s) : dispatch_conv<256, 4>(a, gn_act, upsample != 0, s);
     return waves == 8 ? dispatch_conv<128, 8>(a, gn_act, upsample != 0, s) : dispatch_conv<128, 4>(a, gn_act, upsample != 0, s);
+}
+
+// ---- f32-accurate convolution from three bf16 passes over split operands:  x = x_hi + x_lo, w = w_hi + w_lo (bf16 each),
+//      conv(x, w) ~= conv(x_hi, w_hi) + conv(x_hi, w_lo) + conv(x_lo, w_hi)   (the dropped x_lo * w_lo and the split residuals are
+//      <= 2^-16 |x w| each), f32 accumulation across the passes in the f32 output tensor.
+extern "C" int xm3d_split_bf16_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
+                                    const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, void* hi, void* lo,
+                                    void* ws, void* stream) {
+    XM3D_REQUIRE(x && hi && lo, "split_bf16_nhwc: null pointer");
+    XM3D_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0, "split_bf16_nhwc: C %d must be a multiple of 8", C);
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15) == 0,
+                 "split_bf16_nhwc: tensors must be 16-byte aligned");
+    hipStream_t s = as_stream(stream);
+    const float* affine = nullptr;
+    if (gn_stats) {
+        XM3D_REQUIRE(gamma && beta && groups > 0 && C % groups == 0 && ws && (act == 0 || act == 1 || act == 2), "split_bf16_nhwc: bad GroupNorm arguments");
+        XM3D_REQUIRE(in_shift_bstride == 0 || in_shift_bstride == C, "split_bf16_nhwc: in_shift_bstride must be 0 or C");
+        const int n = int(B) * C;
+        hipLaunchKernelGGL(k_gn_affine, dim3((n + 255) / 256), dim3(256), 0, s, gn_stats, gamma, beta, in_shift, in_shift_bstride, int(B), C, groups,
+                           1.0 / (double(HW) * (C / groups)), eps, static_cast<float*>(ws));
+        affine = static_cast<const float*>(ws);
+    } else {
+        XM3D_REQUIRE(act == 0 && !in_shift, "split_bf16_nhwc: activation / shift need the GroupNorm statistics");
+    }
+    const int64_t n8 = B * HW * (C / 8);
+    hipLaunchKernelGGL(k_split_nhwc, dim3(unsigned((n8 + 255) / 256)), dim3(256), 0, s, x, affine, act, n8, C, HW, static_cast<__bf16*>(hi),
+                       static_cast<__bf16*>(lo));
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+// out (f32) = conv3x3(x bf16, w bf16 packed) + bias + residual (f32; may be `out` itself: accumulate in place)
+extern "C" int xm3d_conv3x3_nhwc_f32acc(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,
+                                        const float* bias, int32_t bias_bstride, const float* residual, float* out, double* stats_out,
+                                        int32_t groups_out, int32_t upsample, int32_t waves, void* stream) {
+    XM3D_REQUIRE(x && wpacked && out, "conv3x3_nhwc_f32acc: null pointer");
+    XM3D_REQUIRE(waves == 0 || waves == 4 || waves == 8, "conv3x3_nhwc_f32acc: waves must be 0 (auto), 4 or 8");
+    if (waves == 0) waves = xm3d_conv3x3_default_waves(H, W, cin, cout);
+    const int TH = waves == 8 ? 8 : 4;
+    XM3D_REQUIRE(B > 0 && B < 65536 && H > 0 && W > 0 && H % TH == 0 && W % CV_TW == 0,
+                 "conv3x3_nhwc_f32acc: output %dx%d is not a multiple of the %dx%d pixel tile", H, W, TH, CV_TW);
+    XM3D_REQUIRE(cin > 0 && cin % CV_KC == 0 && (cout_tile == 128 || cout_tile == 256) && cout > 0 && cout % 32 == 0, "conv3x3_nhwc_f32acc: channels unsupported");
+    XM3D_REQUIRE(int64_t(H) * W * (cin > cout ? cin : cout) < (int64_t(1) << 31), "conv3x3_nhwc_f32acc: image too large for 32-bit offsets");
+    XM3D_REQUIRE(bias_bstride == 0 || bias_bstride == cout, "conv3x3_nhwc_f32acc: bias_bstride must be 0 or cout");
+    if (upsample) XM3D_REQUIRE(H % 2 == 0 && W % 2 == 0, "conv3x3_nhwc_f32acc: upsample needs even output dims");
+    if (stats_out)
+        XM3D_REQUIRE(groups_out > 0 && cout % groups_out == 0 && (cout / groups_out) % 4 == 0 && cout_tile / (cout / groups_out) + 2 <= 128,
+                     "conv3x3_nhwc_f32acc: output statistics need a multiple of 4 channels per group (cout %d, groups %d)", cout, groups_out);
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(out) |
+                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(stats_out)) & 15) == 0,
+                 "conv3x3_nhwc_f32acc: tensors must be 16-byte aligned");
+    ConvArgs a;
+    a.x = static_cast<const __bf16*>(x);
+    a.wp = static_cast<const __bf16*>(wpacked);
+    a.affine = nullptr;
+    a.bias = bias;
+    a.residual = reinterpret_cast<const __bf16*>(residual);  // f32 in this variant (the kernel casts back)
+    a.out = reinterpret_cast<__bf16*>(out);
+    a.stats_out = stats_out;
+    a.B = int(B), a.H = H, a.W = W, a.cin = cin, a.cout = cout;
+    a.bias_bstride = bias_bstride;
+    a.groups_out = stats_out ? groups_out : 1;
+    a.cg_out = stats_out ? cout / groups_out : cout;
+    a.tiles_x = W / CV_TW;
+    a.tiles_y = H / TH;
+    a.nct = (cout + cout_tile - 1) / cout_tile;
+    hipStream_t s = as_stream(stream);
+    if (cout_tile == 256) {
+        if (waves == 8) return upsample ? launch_conv_f32acc<256, true, 8>(a, s) : launch_conv_f32acc<256, false, 8>(a, s);
+        return upsample ? launch_conv_f32acc<256, true, 4>(a, s) : launch_conv_f32acc<256, false, 4>(a, s);
+    }
+    if (waves == 8) return upsample ? launch_conv_f32acc<128, true, 8>(a, s) : launch_conv_f32acc<128, false, 8>(a, s);
+    return upsample ? launch_conv_f32acc<128, true, 4>(a, s) : launch_conv_f32acc<128, false, 4>(a, s);
 }

@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .sd_model import ACT_NONE, ACT_RELU, AutoencoderKL, UNetModel, _gn_f32, _packed, fused_conv_ok, gn_act
+from .sd_model import ACT_NONE, ACT_RELU, AutoencoderKL, UNetModel, _gn_f32, _packed, _packed_split, fused_conv_ok, gn_act
 
 SCALE_FACTOR = 0.18215
 # sqrt(alphas_cumprod[0]) and sqrt(1 - alphas_cumprod[0]) of the "ldm_linear" schedule
@@ -326,11 +326,15 @@ class GNBottleneck(nn.Module):
             # the 3x3 convolution on the HIP kernel: conv1's GroupNorm + ReLU are applied while its input tile is staged (one
             # statistics pass over conv1's output instead of statistics + apply), and the moments for conv2's own GroupNorm come
             # out of the epilogue (its apply pass, which conv3 - a library 1x1 convolution - needs materialised, skips the statistics)
-            packed, tile, _ = _packed(self.conv2)
             gamma, beta = _gn_f32(self.conv1.norm)
             n1 = self.conv1.norm
-            c2 = ops.conv3x3(c1, packed, self.conv2.out_channels, tile, gn=(ops.gn_stats_of(c1, n1.num_groups), gamma, beta, n1.eps, n1.num_groups, "relu"),
-                             stats_groups=self.conv2.norm.num_groups)
+            gn = (ops.gn_stats_of(c1, n1.num_groups), gamma, beta, n1.eps, n1.num_groups, "relu")
+            if c1.dtype == torch.float32:  # fp32 configuration: the f32-accurate form on split bf16 operands
+                ph, pl, tile, _ = _packed_split(self.conv2)
+                c2 = ops.conv3x3_f32(c1, ph, pl, self.conv2.out_channels, tile, gn=gn, stats_groups=self.conv2.norm.num_groups)
+            else:
+                packed, tile, _ = _packed(self.conv2)
+                c2 = ops.conv3x3(c1, packed, self.conv2.out_channels, tile, gn=gn, stats_groups=self.conv2.norm.num_groups)
             return self.conv3(gn_act(self.conv2.norm, c2, ACT_RELU), residual=res, relu=True)
         return self.conv3(self.conv2(gn_act(self.conv1.norm, c1, ACT_RELU)), residual=res, relu=True)
 

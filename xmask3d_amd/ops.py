@@ -509,6 +509,68 @@ def conv3x3_pack_weight(weight):
     return packed, tile
 
 
+def conv3x3_f32_supported(x, cout, upsample=False):
+    """shapes the f32-accurate convolution takes: channels-last f32, the kernel's tile constraints"""
+    if not (is_nhwc(x) and x.dtype == torch.float32):
+        return False
+    _, cin, H, W = x.shape
+    if upsample:
+        H, W = 2 * H, 2 * W
+    return H % 4 == 0 and W % 32 == 0 and cin % 64 == 0 and cout % 32 == 0 and cout >= 128
+
+
+def conv3x3_pack_weight_split(weight):
+    """f32 Conv2d weight (cout, cin, 3, 3) -> (packed hi, packed lo, cout tile): the bf16 split w = hi + lo of the f32-accurate convolution"""
+    w = weight.detach().float()
+    hi = w.to(torch.bfloat16)
+    lo = (w - hi.float()).to(torch.bfloat16)
+    ph, tile = conv3x3_pack_weight(hi)
+    pl, _ = conv3x3_pack_weight(lo)
+    return ph, pl, tile
+
+
+def conv3x3_f32(x, packed_hi, packed_lo, cout, tile, bias=None, gn=None, residual=None, stats_groups=None, upsample=False, in_shift=None, waves=0):
+    """conv3x3(act(GroupNorm(x))) + bias (+ residual) on channels-last f32 tensors, to f32 accuracy, on the bf16 matrix cores: one split
+    pass (x -> hi + lo bf16, the GroupNorm affine + activation applied on the way) and three accumulating convolution launches
+    (hi*w_hi + hi*w_lo + lo*w_hi; see xm3d.h).  Arguments as conv3x3; bias / residual / result f32."""
+    if not conv3x3_f32_supported(x, cout, upsample):
+        raise TypeError(f"conv3x3_f32: unsupported input {tuple(x.shape)} {x.dtype}")
+    B, cin, Hi, Wi = x.shape
+    H, W = (2 * Hi, 2 * Wi) if upsample else (Hi, Wi)
+    hi = torch.empty((B, cin, Hi, Wi), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
+    lo = torch.empty_like(hi)
+    stats_in = gamma = beta = ws = None
+    eps, G, act, sstride = 0.0, 0, 0, 0
+    if gn is not None:
+        stats_in, gamma, beta, eps, G = gn[:5]
+        act = 2 if (len(gn) > 5 and gn[5] == "relu") else 1
+        ws = torch.empty(B * cin * 2, dtype=torch.float32, device=x.device)
+        if in_shift is not None:
+            sstride = cin if (in_shift.numel() == B * cin and B > 1) else 0
+    elif in_shift is not None:
+        raise TypeError("conv3x3_f32: in_shift needs gn")
+    check(lib().xm3d_split_bf16_nhwc(_ptr(x), B, Hi * Wi, cin, _ptr(stats_in), _ptr(gamma), _ptr(beta), _ptr(in_shift), sstride, float(eps), int(G), act,
+                                     _ptr(hi), _ptr(lo), _ptr(ws), _stream()), "xm3d_split_bf16_nhwc")
+    out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
+    bstride = 0
+    if bias is not None:
+        if bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() not in (cout, B * cout):
+            raise TypeError("conv3x3_f32: bias must be a contiguous f32 (cout,) or (B, cout) tensor")
+        bstride = cout if (bias.numel() == B * cout and B > 1) else 0
+    if residual is not None and not (is_nhwc(residual) and residual.dtype == torch.float32 and residual.shape == out.shape):
+        raise TypeError("conv3x3_f32: residual must be a channels-last f32 tensor of the output's shape")
+    stats_out = torch.zeros(B * stats_groups * 2, dtype=torch.float64, device=x.device) if stats_groups else None
+    L = lib().xm3d_conv3x3_nhwc_f32acc
+    u, wv = int(bool(upsample)), int(waves) or _CONV_WAVES
+    check(L(_ptr(hi), B, H, W, cin, _ptr(packed_hi), cout, tile, _ptr(bias), bstride, _ptr(residual), _ptr(out), None, 0, u, wv, _stream()), "xm3d_conv3x3_nhwc_f32acc")
+    check(L(_ptr(hi), B, H, W, cin, _ptr(packed_lo), cout, tile, None, 0, _ptr(out), _ptr(out), None, 0, u, wv, _stream()), "xm3d_conv3x3_nhwc_f32acc")
+    check(L(_ptr(lo), B, H, W, cin, _ptr(packed_hi), cout, tile, None, 0, _ptr(out), _ptr(out), _ptr(stats_out), int(stats_groups or 0), u, wv, _stream()),
+          "xm3d_conv3x3_nhwc_f32acc")
+    if stats_out is not None:
+        out._xm3d_gn_stats = (stats_out, int(stats_groups), out.data_ptr())
+    return out
+
+
 # ---- linear layer / 1x1 convolution with fused epilogue (csrc/gemm.hip)
 GEMM_ACTS = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "geglu": 3}
 
