@@ -249,14 +249,15 @@ int xm3d_conv3x3_default_waves(int32_t H, int32_t W, int32_t cin, int32_t cout);
 /* ---- the same convolution to f32 accuracy from bf16 matrix-core passes (conv.hip): the fp32 configuration of the frozen nets (the
  * reference's own arithmetic, torch.nn.Conv2d in f32) on split operands: x = x_hi + x_lo, w = w_hi + w_lo (bf16 each),
  *   conv(x, w) = conv(x_hi, w_hi) + conv(x_hi, w_lo) + conv(x_lo, w_hi)   + O(2^-16 |x w|),   accumulated in the f32 output.
- *   xm3d_split_bf16_nhwc     : x (B, H*W, C) f32 -> hi, lo bf16 (same shape); with gn_stats: y = act(GroupNorm(x + in_shift)) is split
+ *   xm3d_split_bf16_nhwc     : x (B, H*W, C) f32 -> hi, lo [, lo2: a third term, or NULL] bf16 (same shape); with gn_stats: y = act(GroupNorm(x + in_shift)) is split
  *                              (act 0 none, 1 SiLU, 2 ReLU; ws = xm3d_conv3x3_ws_bytes(B, C) bytes of scratch)
  *   xm3d_conv3x3_nhwc_f32acc : out f32 (B, H, W, cout) = conv3x3(x bf16, packed bf16 weights) + bias + residual f32 (residual may be `out`:
  *                              accumulation in place); stats_out as xm3d_conv3x3_nhwc (moments of the f32 values written).
- *   A full f32-accurate layer = one split + three accumulating launches (ops.conv3x3_f32).  Same shape constraints as xm3d_conv3x3_nhwc. */
+ *   A full layer = one split + three accumulating launches (two terms: 2e-5 of max|out|) or six (three terms, hi*hi + hi*lo + lo*hi +
+ *   hi*lo2 + lo2*hi + lo*lo: f32-exact to ~1e-6) (ops.conv3x3_f32).  Same shape constraints as xm3d_conv3x3_nhwc. */
 int xm3d_split_bf16_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
-                         const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, void* hi, void* lo, void* ws,
-                         void* stream);
+                         const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, void* hi, void* lo, void* lo2,
+                         void* ws, void* stream);
 int xm3d_conv3x3_nhwc_f32acc(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,
                              const float* bias, int32_t bias_bstride, const float* residual, float* out, double* stats_out, int32_t groups_out,
                              int32_t upsample, int32_t waves, void* stream);

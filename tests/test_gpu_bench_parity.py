@@ -130,13 +130,15 @@ FP32_SPLIT = {"pred_3d": 5e-5, "pred_masks": 4e-3, "mask_embed": 5e-3, "mask_emb
               "fused_rel": 4e-3, "point_logits_abs": 2e-3}
 
 
-@pytest.mark.parametrize("mode", ["fp32_graph_nhwc", "bf16_bench", "fp32_split_conv"])
+@pytest.mark.parametrize("mode", ["fp32_graph_nhwc", "bf16_bench", "fp32_split_conv", "fp32_library_conv"])
 def test_configuration_matches_oracle_per_stage(dev, setup, mode, monkeypatch):
     from xmask3d_amd import pipeline
 
     cfg, cpu, scenes = setup
-    if mode == "fp32_split_conv":
-        monkeypatch.setenv("XM3D_CONV_F32", "hip")
+    # fp32_graph_nhwc = the fp32 configuration as shipped (3x3 ResnetBlock convolutions: three-term split operands on the bf16 matrix
+    # cores, ~1e-6 per layer); fp32_library_conv = the same with the library's f32 convolutions; fp32_split_conv = the two-term opt-in
+    if mode in ("fp32_split_conv", "fp32_library_conv"):
+        monkeypatch.setenv("XM3D_CONV_F32", "hip" if mode == "fp32_split_conv" else "library")
     dtype = torch.bfloat16 if mode == "bf16_bench" else torch.float32
     model = pipeline.make_inference_model(cpu, dev, dtype, channels_last=True, graphs=True)
     # bf16: 2 scenes x 5 views in ONE forward (batch 10), as bench does; fp32: one scene per forward, like bench's fp32 leg

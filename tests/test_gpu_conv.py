@@ -253,13 +253,13 @@ def test_conv3x3_cout_not_a_multiple_of_the_tile(dev, waves):
         assert out.shape == ref.shape and (out.float() - ref).abs().max().item() < 1e-2 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("waves", [8, 4])
+@pytest.mark.parametrize("waves,terms", [(8, 2), (4, 3), (8, 3)])
 @pytest.mark.parametrize("B,cin,cout,H,W,mode", [(2, 128, 128, 16, 64, "gn_res"), (1, 256, 512, 8, 32, "plain"), (2, 64, 256, 16, 64, "ups"),
                                                   (1, 320, 320, 8, 32, "gn_res"), (1, 512, 512, 16, 32, "gn_bias2")])
-def test_conv3x3_f32_accurate_form_matches_f64(dev, B, cin, cout, H, W, mode, waves):
+def test_conv3x3_f32_accurate_form_matches_f64(dev, B, cin, cout, H, W, mode, waves, terms):
     """ops.conv3x3_f32 (the fp32 configuration's convolution: split bf16 operands, three accumulating matrix-core passes) against an
-    f64 evaluation of the same layer.  Bound 2e-5 of max|out| (dropped lo*lo products and split residuals are 2^-16 relative each,
-    random in sign; the f32 library convolution itself sits at ~1e-6) - the same bound as the split-operand sparse convolution."""
+    f64 evaluation of the same layer.  Two-term split: bound 2e-5 of max|out| (the same bound as the split-operand sparse convolution);
+    three-term split (six passes): 1e-6, the level of an f32 library convolution's own rounding."""
     from xmask3d_amd import ops
 
     g = torch.Generator().manual_seed(cin + 5 * cout + H + waves)
@@ -269,14 +269,14 @@ def test_conv3x3_f32_accurate_form_matches_f64(dev, B, cin, cout, H, W, mode, wa
     w = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev)
     per_sample = mode == "gn_bias2"
     bias = (0.3 * torch.randn((B, cout) if per_sample else (cout,), generator=g)).to(dev)
-    ph, pl, tile = ops.conv3x3_pack_weight_split(w)
+    packs, tile = ops.conv3x3_pack_weight_split(w, terms)
     assert ops.conv3x3_f32_supported(x, cout, mode == "ups")
     xd = x.double()
     if mode in ("gn_res", "gn_bias2"):
         gamma, beta = (1 + 0.2 * torch.randn(cin, generator=g)).to(dev), (0.2 * torch.randn(cin, generator=g)).to(dev)
         res = _nhwc(torch.randn(B, cout, H, W, generator=g).to(dev)) if mode == "gn_res" else None
         gs = 32 if (cout // 32) % 4 == 0 else None
-        out = ops.conv3x3_f32(x, ph, pl, cout, tile, bias=bias, gn=(ops.gn_stats_of(x, G), gamma, beta, 1e-6, G), residual=res, stats_groups=gs, waves=waves)
+        out = ops.conv3x3_f32(x, packs, cout, tile, bias=bias, gn=(ops.gn_stats_of(x, G), gamma, beta, 1e-6, G), residual=res, stats_groups=gs, waves=waves)
         xin = F.silu(F.group_norm(xd, G, gamma.double(), beta.double(), 1e-6))
         ref = F.conv2d(xin, w.double(), None, padding=1) + bias.double().view(-1 if per_sample else 1, cout, 1, 1)
         if res is not None:
@@ -287,9 +287,10 @@ def test_conv3x3_f32_accurate_form_matches_f64(dev, B, cin, cout, H, W, mode, wa
             want = torch.stack([o.sum((2, 3)), (o * o).sum((2, 3))], -1)
             assert ((st - want).abs() / (want.abs() + 1.0)).max().item() < 1e-5
     else:
-        out = ops.conv3x3_f32(x, ph, pl, cout, tile, bias=bias, upsample=mode == "ups", waves=waves)
+        out = ops.conv3x3_f32(x, packs, cout, tile, bias=bias, upsample=mode == "ups", waves=waves)
         xin = F.interpolate(xd, scale_factor=2.0, mode="nearest") if mode == "ups" else xd
         ref = F.conv2d(xin, w.double(), bias.double(), padding=1)
     assert out.dtype == torch.float32 and out.shape == ref.shape and out.is_contiguous(memory_format=torch.channels_last)
     err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
-    assert err < 2e-5, err
+    # two terms: dropped lo*lo and split residuals, 2^-18 each; three terms: the f32 accumulation of the partial sums is what is left
+    assert err < (2e-5 if terms == 2 else 1e-6), err

@@ -65,7 +65,7 @@ _SIGS = {
     "xm3d_conv3x3_nhwc": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_i32, c_i32,
                                          c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_conv3x3_default_waves": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
-    "xm3d_split_bf16_nhwc": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp]),
+    "xm3d_split_bf16_nhwc": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_conv3x3_nhwc_f32acc": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
     "xm3d_gemm_col_tile": (ctypes.c_int, [c_i32]),
     "xm3d_gemm_packed_elems": (ctypes.c_int64, [c_i32, c_i32, c_i32]),

@@ -428,7 +428,7 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3_f32acc(const ConvArgs a)
 // f32 (B, H*W, C) -> bf16 hi / lo with x = hi + lo (+ <= 2^-17 |x|), optionally through y = act(x * scale + shift) with the
 // per-(image, channel) GroupNorm affine of k_gn_affine: the operand split of the f32-accurate convolution.  One thread = 8 channels.
 __global__ void k_split_nhwc(const float* __restrict__ x, const float* __restrict__ affine, int act, int64_t n8, int C, int64_t hw,
-                             __bf16* __restrict__ hi, __bf16* __restrict__ lo) {
+                             __bf16* __restrict__ hi, __bf16* __restrict__ lo, __bf16* __restrict__ lo2) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n8) return;
     const int c8 = C / 8;
@@ -446,14 +446,17 @@ __global__ void k_split_nhwc(const float* __restrict__ x, const float* __restric
             v[j] = y;
         }
     }
-    cv_bf16x8 h8, l8;
+    cv_bf16x8 h8, l8, m8;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         h8[j] = (__bf16)v[j];
-        l8[j] = (__bf16)(v[j] - float(h8[j]));
+        const float r1 = v[j] - float(h8[j]);  // exact in f32
+        l8[j] = (__bf16)r1;
+        m8[j] = (__bf16)(r1 - float(l8[j]));   // third term: x = hi + lo + lo2 to 2^-25 |x|
     }
     *reinterpret_cast<cv_bf16x8*>(hi + i * 8) = h8;
     *reinterpret_cast<cv_bf16x8*>(lo + i * 8) = l8;
+    if (lo2) *reinterpret_cast<cv_bf16x8*>(lo2 + i * 8) = m8;
 }
 
 // OHWI (cout, 9, cin) bf16 -> fragment-ordered weight streams [cout tile][32-row block][chunk][tap][k-step][lane][8]: lane l of
@@ -644,7 +647,7 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
 //      <= 2^-16 |x w| each), f32 accumulation across the passes in the f32 output tensor.
 extern "C" int xm3d_split_bf16_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
                                     const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, void* hi, void* lo,
-                                    void* ws, void* stream) {
+                                    void* lo2, void* ws, void* stream) {
     XM3D_REQUIRE(x && hi && lo, "split_bf16_nhwc: null pointer");
     XM3D_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0, "split_bf16_nhwc: C %d must be a multiple of 8", C);
     XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15) == 0,
@@ -663,7 +666,7 @@ extern "C" int xm3d_split_bf16_nhwc(const float* x, int64_t B, int64_t HW, int32
     }
     const int64_t n8 = B * HW * (C / 8);
     hipLaunchKernelGGL(k_split_nhwc, dim3(unsigned((n8 + 255) / 256)), dim3(256), 0, s, x, affine, act, n8, C, HW, static_cast<__bf16*>(hi),
-                       static_cast<__bf16*>(lo));
+                       static_cast<__bf16*>(lo), static_cast<__bf16*>(lo2));
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }

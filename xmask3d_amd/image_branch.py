@@ -330,8 +330,8 @@ class GNBottleneck(nn.Module):
             n1 = self.conv1.norm
             gn = (ops.gn_stats_of(c1, n1.num_groups), gamma, beta, n1.eps, n1.num_groups, "relu")
             if c1.dtype == torch.float32:  # fp32 configuration: the f32-accurate form on split bf16 operands
-                ph, pl, tile, _ = _packed_split(self.conv2)
-                c2 = ops.conv3x3_f32(c1, ph, pl, self.conv2.out_channels, tile, gn=gn, stats_groups=self.conv2.norm.num_groups)
+                packs, tile, _ = _packed_split(self.conv2)
+                c2 = ops.conv3x3_f32(c1, packs, self.conv2.out_channels, tile, gn=gn, stats_groups=self.conv2.norm.num_groups)
             else:
                 packed, tile, _ = _packed(self.conv2)
                 c2 = ops.conv3x3(c1, packed, self.conv2.out_channels, tile, gn=gn, stats_groups=self.conv2.norm.num_groups)

@@ -519,26 +519,30 @@ def conv3x3_f32_supported(x, cout, upsample=False):
     return H % 4 == 0 and W % 32 == 0 and cin % 64 == 0 and cout % 32 == 0 and cout >= 128
 
 
-def conv3x3_pack_weight_split(weight):
-    """f32 Conv2d weight (cout, cin, 3, 3) -> (packed hi, packed lo, cout tile): the bf16 split w = hi + lo of the f32-accurate convolution"""
-    w = weight.detach().float()
-    hi = w.to(torch.bfloat16)
-    lo = (w - hi.float()).to(torch.bfloat16)
-    ph, tile = conv3x3_pack_weight(hi)
-    pl, _ = conv3x3_pack_weight(lo)
-    return ph, pl, tile
+def conv3x3_pack_weight_split(weight, terms=3):
+    """f32 Conv2d weight (cout, cin, 3, 3) -> ([packed term 0, 1(, 2)], cout tile): the bf16 split w = t0 + t1 (+ t2) of the f32-accurate
+    convolution (two terms: 2^-18 |w| left over; three: 2^-25)"""
+    r = weight.detach().float()
+    packs, tile = [], None
+    for _ in range(terms):
+        t = r.to(torch.bfloat16)
+        r = r - t.float()
+        p_, tile = conv3x3_pack_weight(t)
+        packs.append(p_)
+    return packs, tile
 
 
-def conv3x3_f32(x, packed_hi, packed_lo, cout, tile, bias=None, gn=None, residual=None, stats_groups=None, upsample=False, in_shift=None, waves=0):
+def conv3x3_f32(x, packs, cout, tile, bias=None, gn=None, residual=None, stats_groups=None, upsample=False, in_shift=None, waves=0):
     """conv3x3(act(GroupNorm(x))) + bias (+ residual) on channels-last f32 tensors, to f32 accuracy, on the bf16 matrix cores: one split
-    pass (x -> hi + lo bf16, the GroupNorm affine + activation applied on the way) and three accumulating convolution launches
-    (hi*w_hi + hi*w_lo + lo*w_hi; see xm3d.h).  Arguments as conv3x3; bias / residual / result f32."""
+    pass (x -> bf16 terms, the GroupNorm affine + activation applied on the way) and accumulating convolution launches over the
+    term pairs - len(packs) == 2: x0 w0 + x0 w1 + x1 w0 (2e-5 of max|out|); 3: + x0 w2 + x2 w0 + x1 w1 (~1e-6, the rounding level of an
+    f32 convolution).  Arguments as conv3x3; bias / residual / result f32."""
     if not conv3x3_f32_supported(x, cout, upsample):
         raise TypeError(f"conv3x3_f32: unsupported input {tuple(x.shape)} {x.dtype}")
+    terms = len(packs)
     B, cin, Hi, Wi = x.shape
     H, W = (2 * Hi, 2 * Wi) if upsample else (Hi, Wi)
-    hi = torch.empty((B, cin, Hi, Wi), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last)
-    lo = torch.empty_like(hi)
+    xt = [torch.empty((B, cin, Hi, Wi), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last) for _ in range(terms)]
     stats_in = gamma = beta = ws = None
     eps, G, act, sstride = 0.0, 0, 0, 0
     if gn is not None:
@@ -550,7 +554,7 @@ def conv3x3_f32(x, packed_hi, packed_lo, cout, tile, bias=None, gn=None, residua
     elif in_shift is not None:
         raise TypeError("conv3x3_f32: in_shift needs gn")
     check(lib().xm3d_split_bf16_nhwc(_ptr(x), B, Hi * Wi, cin, _ptr(stats_in), _ptr(gamma), _ptr(beta), _ptr(in_shift), sstride, float(eps), int(G), act,
-                                     _ptr(hi), _ptr(lo), _ptr(ws), _stream()), "xm3d_split_bf16_nhwc")
+                                     _ptr(xt[0]), _ptr(xt[1]), _ptr(xt[2]) if terms == 3 else None, _ptr(ws), _stream()), "xm3d_split_bf16_nhwc")
     out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     bstride = 0
     if bias is not None:
@@ -562,10 +566,12 @@ def conv3x3_f32(x, packed_hi, packed_lo, cout, tile, bias=None, gn=None, residua
     stats_out = torch.zeros(B * stats_groups * 2, dtype=torch.float64, device=x.device) if stats_groups else None
     L = lib().xm3d_conv3x3_nhwc_f32acc
     u, wv = int(bool(upsample)), int(waves) or _CONV_WAVES
-    check(L(_ptr(hi), B, H, W, cin, _ptr(packed_hi), cout, tile, _ptr(bias), bstride, _ptr(residual), _ptr(out), None, 0, u, wv, _stream()), "xm3d_conv3x3_nhwc_f32acc")
-    check(L(_ptr(hi), B, H, W, cin, _ptr(packed_lo), cout, tile, None, 0, _ptr(out), _ptr(out), None, 0, u, wv, _stream()), "xm3d_conv3x3_nhwc_f32acc")
-    check(L(_ptr(lo), B, H, W, cin, _ptr(packed_hi), cout, tile, None, 0, _ptr(out), _ptr(out), _ptr(stats_out), int(stats_groups or 0), u, wv, _stream()),
-          "xm3d_conv3x3_nhwc_f32acc")
+    pairs = [(0, 0), (0, 1), (1, 0)] + ([(0, 2), (2, 0), (1, 1)] if terms == 3 else [])
+    for n, (i, j) in enumerate(pairs):
+        first, last = n == 0, n == len(pairs) - 1
+        check(L(_ptr(xt[i]), B, H, W, cin, _ptr(packs[j]), cout, tile, _ptr(bias) if first else None, bstride if first else 0,
+                _ptr(residual) if first else _ptr(out), _ptr(out), _ptr(stats_out) if last else None, int(stats_groups or 0) if last else 0, u, wv,
+                _stream()), "xm3d_conv3x3_nhwc_f32acc")
     if stats_out is not None:
         out._xm3d_gn_stats = (stats_out, int(stats_groups), out.data_ptr())
     return out

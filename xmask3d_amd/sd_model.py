@@ -62,7 +62,7 @@ def fused_conv_ok(x, conv, upsample=False):
         return False
     if x.dtype == torch.bfloat16:
         return ops.conv3x3_supported(x, conv.out_channels, upsample)
-    return (x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and os.environ.get("XM3D_CONV_F32", "library") == "hip"
+    return (x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and conv_f32_terms() > 0
             and ops.conv3x3_f32_supported(x, conv.out_channels, upsample))
 
 
@@ -77,14 +77,21 @@ def _packed(conv):
     return c[1], c[2], c[3]
 
 
+def conv_f32_terms():
+    """XM3D_CONV_F32: "hip3" (default: three-term split, six bf16 MFMA passes, ~1e-6 per layer - the rounding level of an f32
+    convolution), "hip" (two-term split, three passes, 2e-5 per layer: opt-in, see fused_conv_ok), "library" (torch / MIOpen f32)"""
+    return {"hip": 2, "hip2": 2, "hip3": 3}.get(os.environ.get("XM3D_CONV_F32", "hip3"), 0)
+
+
 def _packed_split(conv):
-    """(packed hi, packed lo, cout tile, f32 bias) of a frozen f32 Conv2d: the bf16 split of its weight, built once per weight storage"""
+    """(packed weight terms, cout tile, f32 bias) of a frozen f32 Conv2d: the bf16 split of its weight, built once per weight storage"""
     w = conv.weight
-    key = (w.data_ptr(), w._version, w.dtype)
+    terms = conv_f32_terms() or 3
+    key = (w.data_ptr(), w._version, w.dtype, terms)
     c = conv.__dict__.get("_xm3d_pack_split")
     if c is None or c[0] != key:
-        ph, pl, tile = ops.conv3x3_pack_weight_split(w)
-        c = conv.__dict__["_xm3d_pack_split"] = (key, ph, pl, tile, None if conv.bias is None else conv.bias.detach().float().contiguous())
+        packs, tile = ops.conv3x3_pack_weight_split(w, terms)
+        c = conv.__dict__["_xm3d_pack_split"] = (key, packs, tile, None if conv.bias is None else conv.bias.detach().float().contiguous())
     return c[1:]
 
 
@@ -103,8 +110,8 @@ def gn_silu_conv3x3(norm, conv, x, pend=None, bias=None, residual=None):
     gamma, beta = _gn_f32(norm)
     stats = ops.gn_stats_of(x, norm.num_groups, shift=pend)
     if x.dtype == torch.float32:
-        ph, pl, tile, own_bias = _packed_split(conv)
-        return ops.conv3x3_f32(x, ph, pl, conv.out_channels, tile, bias=own_bias if bias is None else bias,
+        packs, tile, own_bias = _packed_split(conv)
+        return ops.conv3x3_f32(x, packs, conv.out_channels, tile, bias=own_bias if bias is None else bias,
                                gn=(stats, gamma, beta, norm.eps, norm.num_groups), residual=residual,
                                stats_groups=32 if (conv.out_channels // 32) % 4 == 0 else None,
                                in_shift=None if pend is None else pend.detach().float().contiguous())
@@ -117,8 +124,8 @@ def gn_silu_conv3x3(norm, conv, x, pend=None, bias=None, residual=None):
 def plain_conv3x3(conv, x, upsample=False):
     """conv(x) + bias (x nearest-upsampled 2x first if asked), moments of the result left on it"""
     if x.dtype == torch.float32:
-        ph, pl, tile, own_bias = _packed_split(conv)
-        return ops.conv3x3_f32(x, ph, pl, conv.out_channels, tile, bias=own_bias, upsample=upsample,
+        packs, tile, own_bias = _packed_split(conv)
+        return ops.conv3x3_f32(x, packs, conv.out_channels, tile, bias=own_bias, upsample=upsample,
                                stats_groups=32 if (conv.out_channels // 32) % 4 == 0 else None)
     packed, tile, own_bias = _packed(conv)
     return ops.conv3x3(x, packed, conv.out_channels, tile, bias=own_bias, upsample=upsample,
