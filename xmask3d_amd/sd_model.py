@@ -170,10 +170,19 @@ def _packed_lin(mods, act=None):
     return c[1:]
 
 
-def lin(mods, x, act=None, residual=None):
-    """act(x @ W^T + b) (+ residual) over the last dimension in one launch; mods: a Linear / 1x1 Conv2d or a list of them (stacked)"""
+def lin(mods, x, act=None, residual=None, with_bias=True):
+    """act(x @ W^T + b) (+ residual) over the last dimension in one launch; mods: a Linear / 1x1 Conv2d or a list of them (stacked).
+    with_bias False: the product alone (the caller folds the bias into a later epilogue)"""
     packed, tile, bias, n = _packed_lin(mods, act)
-    return ops.gemm(x, packed, n, tile, bias=bias, act=act, residual=residual)
+    return ops.gemm(x, packed, n, tile, bias=bias if with_bias else None, act=act, residual=residual)
+
+
+def conv1x1_nobias(conv, x):
+    """a 1x1 convolution without its bias: the token GEMM on k_gemm where that wins (channels-last bf16 inference), else the library"""
+    if fused_nhwc(x) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and gemm_ok(tokens_of(x), conv.out_channels) \
+            and os.environ.get("XM3D_GEMM_1X1", "hip") != "library":
+        return image_of(lin(conv, tokens_of(x), with_bias=False), x.shape[2], x.shape[3])
+    return conv_nobias(conv, x)
 
 
 def tokens_of(x):
@@ -240,7 +249,7 @@ class VaeResBlock(nn.Module):
             h = gn_silu_conv3x3(self.norm1, self.conv1, x, pend=pend)
             bias, skip = None, x
             if self.in_channels != self.out_channels:
-                skip = conv_nobias(self.nin_shortcut, x)
+                skip = conv1x1_nobias(self.nin_shortcut, x)
                 bias = self.conv2.bias.float() + self.nin_shortcut.bias.float()
                 if pend is not None:  # the 1x1 shortcut of a constant: W @ pend
                     bias = bias + (self.nin_shortcut.weight.flatten(1) @ pend.to(self.nin_shortcut.weight.dtype)).float()
@@ -282,6 +291,15 @@ class VaeAttnBlock(nn.Module):
     def forward(self, x):
         h = gn_act(self.norm, x)
         b, c, hh, ww = h.shape
+        if fused_nhwc(h) and gemm_ok(tokens_of(h), 3 * c) and (hh * ww) % 4 == 0 and hh * ww <= 8192 \
+                and os.environ.get("XM3D_GEMM_1X1", "hip") != "library":
+            # channels-last: q, k, v from ONE token GEMM (k_gemm), scores / softmax / product as below, proj_out + bias + skip in the
+            # epilogue of another - no transposes, no separate bias / residual pass
+            qkv = lin([self.q, self.k, self.v], tokens_of(h))
+            q, k, v = (qkv[..., i * c:(i + 1) * c] for i in range(3))
+            s_ = torch.bmm(q, k.transpose(1, 2), out_dtype=torch.float32)
+            o = torch.bmm(ops.softmax_rows(s_, c ** -0.5), v)
+            return image_of(lin(self.proj_out, o, residual=tokens_of(x)), hh, ww)
         q = self.q(h).reshape(b, 1, c, hh * ww).transpose(2, 3)
         k = self.k(h).reshape(b, 1, c, hh * ww).transpose(2, 3)
         v = self.v(h).reshape(b, 1, c, hh * ww).transpose(2, 3)
@@ -463,7 +481,7 @@ class UNetResBlock(nn.Module):
             h = gn_silu_conv3x3(self.in_layers[0], self.in_layers[2], x, bias=bias1)
             bias, skip = None, x
             if not isinstance(self.skip_connection, nn.Identity):
-                skip = conv_nobias(self.skip_connection, x)
+                skip = conv1x1_nobias(self.skip_connection, x)
                 bias = self.out_layers[3].bias.float() + self.skip_connection.bias.float()
             return gn_silu_conv3x3(self.out_layers[0], self.out_layers[3], h, bias=bias, residual=skip)
         if fused_nhwc(x):  # first conv's bias + the embedding term ride in the second GroupNorm's shift
