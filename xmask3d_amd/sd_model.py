@@ -54,9 +54,11 @@ def conv_nobias(conv: nn.Conv2d, x):
 # ---- fused GroupNorm -> SiLU -> conv3x3 (csrc/conv.hip, xm3d_conv3x3_nhwc): the ResnetBlock halves of both frozen nets
 def fused_conv_ok(x, conv, upsample=False):
     """channels-last inference on a shape the HIP convolution takes: bf16 (xm3d_conv3x3_nhwc; XM3D_CONV=library switches it off for A/B
-    runs) or, OPT-IN with XM3D_CONV_F32=hip, f32 through the split-operand form (ops.conv3x3_f32: three bf16 matrix-core passes, 2e-5
-    per layer).  The opt-in makes the fp32 configuration 1.35 x faster but spends most of its parity margin - per-point logits 6e-4
-    instead of 1.5e-4 against the oracle (north_star: 1e-3) - so the default fp32 path keeps the library's exact-f32 convolutions."""
+    runs) or f32 through the split-operand form (ops.conv3x3_f32, the fp32 configuration): by default three bf16 terms per operand
+    and six matrix-core passes, ~1e-6 per layer - the rounding level of an f32 convolution, per-stage parity of the fp32 forward
+    unchanged against the library's f32 convolutions.  XM3D_CONV_F32=hip selects the two-term / three-pass form (2e-5 per layer;
+    fp32 configuration 1.35 x faster, but per-point logits 6e-4 instead of 1.5e-4 against the oracle - north_star: 1e-3 - so it stays
+    an opt-in), XM3D_CONV_F32=library the torch convolutions (conv_f32_terms)."""
     if not (fused_nhwc(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
             and conv.groups == 1 and x.shape[1] == conv.in_channels and os.environ.get("XM3D_CONV", "hip") != "library"):
         return False
