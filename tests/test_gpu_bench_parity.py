@@ -149,7 +149,7 @@ def test_configuration_matches_oracle_per_stage(dev, setup, mode, monkeypatch):
     off = batch["point_offsets"]
     bounds = BF16 if mode == "bf16_bench" else (FP32_SPLIT if mode == "fp32_split_conv" else FP32)
     worst = {}
-    for (si, v) in (((0, 0), (0, 3), (1, 2)) if mode == "bf16_bench" else ((0, 0), (0, 3))):   # through the oracle (5 s each)
+    for (si, v) in (((0, 0), (1, 2)) if mode == "bf16_bench" else ((0, 0), (0, 3))):   # through the CPU oracle (20 - 40 s of host time each)
         b = si * 5 + v
         ref = oracle_view(cpu, scenes[si], v, (si, v))
         rep = stage_report(out, b, slice(off[b], off[b + 1]), ref)
