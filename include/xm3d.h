@@ -179,9 +179,17 @@ int xm3d_bn_bwd_apply(const float* gy, const float* x, int64_t n, int32_t c, con
  * Fused GroupNorm (+SiLU) over NCHW activations (replaces nn.GroupNorm(32,C) [+ x*sigmoid(x)] inside the SD
  * VAE/UNet blocks the extractor runs, models/modeling/meta_arch/ldm.py:386-490, and the GN of the projection
  * bottlenecks, backbone/feature_extractor.py:40-47).  x, y: (B,C,H*W) contiguous, dtype 0 = f32, 1 = bf16;
- * gamma/beta: (C) in the SAME dtype or NULL; silu: 0 = none, 1 = SiLU, 2 = ReLU; stats_ws: B*G*2 doubles of
- * scratch.  y may alias x.
+ * gamma/beta: (C) in the SAME dtype or NULL; silu: 0 = none, 1 = SiLU, 2 = ReLU; stats_ws: xm3d_gn_stats_doubles_nchw(B, C, hw, G)
+ * doubles of scratch.  y may alias x.
+ * STATISTICS BUFFERS of this section and of the convolution below: the first B*G*2 doubles receive the moments (sum, sum of
+ * squares per (sample, group)); the doubles behind them hold the per-workgroup partial pairs the moments are summed from in a FIXED
+ * order - no floating-point atomics, so the moments (and everything computed from them) are bit-identical from run to run, like the
+ * reference's inference forward (no atomics in ms_deform_im2col_cuda.cuh:242-304 or in nn.GroupNorm).  Consumers
+ * (xm3d_group_norm_nhwc_apply, xm3d_conv3x3_nhwc's gn_stats) only read the first B*G*2 doubles.
  * ------------------------------------------------------------------------- */
+int64_t xm3d_gn_stats_doubles_nchw(int64_t B, int32_t C, int32_t hw, int32_t G);
+/* size in doubles of the `stats` / `stats_ws` argument of the channels-last calls (xm3d_group_norm_nhwc[_res], _stats, xm3d_bias_residual_stats_nhwc) */
+int64_t xm3d_gn_stats_doubles_nhwc(int64_t B, int32_t C, int32_t hw, int32_t G, int32_t dtype);
 int xm3d_group_norm(const void* x, int32_t dtype, int64_t B, int32_t C, int32_t hw, int32_t G, const void* gamma,
                     const void* beta, float eps, int32_t silu, void* y, double* stats_ws, void* stream);
 /* Same for channels-last activations: x, y are (B, H*W, C) contiguous (NHWC); C a multiple of 4 (f32) / 8 (bf16), G <= 64.
@@ -199,7 +207,7 @@ int xm3d_group_norm_nhwc_res(const void* x, const void* shift, int32_t shift_bst
                              double* stats_ws, void* stream);
 
 /* out = a + b + bias[c] like xm3d_bias_residual_nhwc, plus the GroupNorm statistics of `out` (sum, sum of squares per (sample,
- * group), over the values as stored) into stats (B*G*2 doubles, zeroed here): the GroupNorm that consumes `out` next - norm1 of
+ * group), over the values as stored) into stats (xm3d_gn_stats_doubles_nhwc doubles, moments first): the GroupNorm that consumes `out` next - norm1 of
  * the following ResBlock, the norm of an attention block - then runs xm3d_group_norm_nhwc_apply with them and skips its
  * statistics pass.  a may be NULL; (B, H*W, C) channels-last, C a multiple of 4 (f32) / 8 (bf16), G <= 64. */
 int xm3d_bias_residual_stats_nhwc(const void* a, const void* b, const void* bias, int32_t dtype, int64_t B, int32_t C, int32_t hw, int32_t G,
@@ -228,7 +236,9 @@ int xm3d_group_norm_nhwc_apply(const void* x, const void* shift, int32_t shift_b
  *       (a convolution bias the producer of x left to its consumer) and gn_stats are the moments of that sum.
  *       gn_stats NULL (act 0): plain convolution of x; upsample = 1 (plain only): x is first nearest-upsampled 2x (ldm Upsample).
  *       bias (cout) f32 with bias_bstride 0, or (B, cout) with bias_bstride = cout (conv bias + timestep-embedding term), or NULL.
- *       stats_out (B, groups_out, 2) f64 or NULL: += moments of the bf16 values stored to out (caller zeroes it).
+ *       stats_out: xm3d_conv3x3_stats_doubles(B, H, W, cout, cout_tile, groups_out, waves) doubles or NULL: the first B*groups_out*2 receive
+ *       the moments of the bf16 values stored to out (written, not accumulated: no zeroing needed); the rest is the scratch of the
+ *       fixed-order reduction (see "STATISTICS BUFFERS" above).
  *       ws: xm3d_conv3x3_ws_bytes(B, cin) bytes of device scratch (the per-(image, channel) affine derived from the moments by a
  *       small kernel in front of the convolution); may be NULL without GroupNorm.
  *       waves: 0 (choose), 8 or 4 - the workgroup geometry, results do not depend on it.
@@ -238,6 +248,7 @@ int xm3d_conv3x3_cout_tile(int32_t cout);
 int64_t xm3d_conv3x3_packed_elems(int32_t cout, int32_t cin, int32_t cout_tile);
 int xm3d_conv3x3_pack_weight(const void* w_ohwi, int32_t cout, int32_t cin, int32_t cout_tile, void* packed, void* stream);
 int64_t xm3d_conv3x3_ws_bytes(int64_t B, int32_t cin);
+int64_t xm3d_conv3x3_stats_doubles(int64_t B, int32_t H, int32_t W, int32_t cout, int32_t cout_tile, int32_t groups_out, int32_t waves);
 int xm3d_conv3x3_nhwc(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,
                       const double* gn_stats, const float* gamma, const float* beta, const float* in_shift, int32_t in_shift_bstride,
                       float eps, int32_t groups, int32_t act, const float* bias, int32_t bias_bstride, const void* residual, void* out, double* stats_out,
@@ -287,8 +298,23 @@ int xm3d_gemm_pack_weight(const void* w, int32_t w_is_f32, int32_t N, int32_t K,
 int xm3d_gemm_default_waves(int64_t M, int32_t N, int32_t col_tile);
 int xm3d_gemm_bf16(const void* x, int64_t M, int32_t K, int64_t ldx, const void* wpacked, int32_t N, int32_t col_tile, const float* bias, int32_t act,
                    const void* residual, int64_t ldr, void* out, int64_t ldo, int32_t waves, void* stream);
-/* GroupNorm moments alone, in the layout the calls above take: stats (B*G*2) f64 <- (sum, sum of squares) of x (+ shift) per
- * (sample, group); x (B, H*W, C) channels-last, dtype 0 = f32 / 1 = bf16; stats is zeroed here. */
+/* ---- implicit-GEMM convolution on the same kernel (gemm.hip, GF_CONV): the convolutions of the frozen nets that the halo-tile kernel
+ * above does not take - ldm's strided Downsample (VAE: F.pad(x, (0,1,0,1)) + Conv2d(3, stride 2, padding 0); UNet: Conv2d(3, stride 2,
+ * padding 1)), the 3x3 convolutions of the 16^2 / 8^2 UNet levels, 1x1 convolutions with large K (models/modeling/meta_arch/ldm.py:386-490
+ * -> torch.nn.Conv2d, cuDNN / MIOpen there).  x (B, Hin, Win, Cin) channels-last bf16, out / residual (B, Ho, Wo, N) bf16:
+ *   out[b, oy, ox, :] = sum_{ky, kx} W[:, ky, kx, :] . x[b, oy * stride - pad_t + ky, ox * stride - pad_l + kx, :] + bias (+ residual)
+ * (taps outside the image are zero: any bottom / right padding follows from Ho, Wo).  The token rows of the GEMM are gathered from the
+ * image while they are staged in LDS - no im2col tensor.  wpacked = xm3d_gemm_pack_weight of W viewed as (N, ksize*ksize*Cin) in
+ * (ky, kx, cin) order (Conv2d.weight.permute(0, 2, 3, 1)); Cin % 64 == 0, N % 32 == 0, ksize 1..3.
+ * Grids smaller than two workgroups per CU run a DETERMINISTIC split-K: the K slices write f32 partial slabs into ws
+ * (xm3d_conv_gemm_ws_bytes(M = B*Ho*Wo, N, K, col_tile) bytes; 0 = no split for this shape) and a second launch adds them in slice
+ * order - bit-reproducible, unlike the atomically accumulated split-K of the library convolutions these calls replace. */
+int64_t xm3d_conv_gemm_ws_bytes(int64_t M, int32_t N, int32_t K, int32_t col_tile);
+int xm3d_conv_gemm_bf16(const void* x, int64_t B, int32_t Hin, int32_t Win, int32_t Cin, const void* wpacked, int32_t N, int32_t col_tile,
+                        int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, const float* bias,
+                        const void* residual, void* out, void* ws, void* stream);
+/* GroupNorm moments alone, in the layout the calls above take: stats[0 .. B*G*2) f64 <- (sum, sum of squares) of x (+ shift) per
+ * (sample, group); x (B, H*W, C) channels-last, dtype 0 = f32 / 1 = bf16; stats holds xm3d_gn_stats_doubles_nhwc doubles. */
 int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,
                                int32_t G, double* stats, void* stream);
 

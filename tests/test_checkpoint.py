@@ -83,3 +83,58 @@ def test_clip_key_names_follow_open_clip():
               "positional_embedding", "ln_final.weight", "text_projection", "logit_scale"):
         assert k in keys
     assert set(ck.map_openclip_state_dict({**{k: 0 for k in keys}, "attn_mask": 0})) == keys
+
+
+class _NotATensor:  # what a Lightning checkpoint's "callbacks" entry pickles (a ModelCheckpoint object)
+    def __init__(self):
+        self.best = 1.0
+
+
+def _stub_model():
+    import types
+
+    ldm = types.SimpleNamespace()
+    m = types.SimpleNamespace(dense_dtype=torch.float32)
+    m.backbone = types.SimpleNamespace(feature_extractor=types.SimpleNamespace(ldm_extractor=types.SimpleNamespace(ldm=ldm)))
+    m.criterion = types.SimpleNamespace(clip=types.SimpleNamespace())
+    m.set_dense_dtype = lambda d: m
+    return m
+
+
+def test_a_refused_frozen_net_file_is_an_error_not_a_silent_random_net(tmp_path, monkeypatch):
+    """sd_model/sd-v1-3.ckpt is a Lightning checkpoint whose `callbacks` entry pickles an object: the tensors-only loader
+    refuses it.  That must not end in a silent run on a seeded random SD UNet: load_pretrained raises, or - with the explicit
+    opt-out - warns and records the problem in the report the driver prints"""
+    import types
+    import warnings
+
+    from xmask3d_amd import checkpoint
+
+    (tmp_path / "sd_model").mkdir()
+    torch.save({"state_dict": {"w": torch.zeros(2)}, "callbacks": {"ckpt": _NotATensor()}}, tmp_path / "sd_model" / "sd-v1-3.ckpt")
+    monkeypatch.setenv("XM3D_PRETRAINED_ROOT", str(tmp_path))
+    monkeypatch.delenv("XM3D_ALLOW_PARTIAL_PRETRAINED", raising=False)
+    cfg = types.SimpleNamespace()
+    assert checkpoint.find_pretrained(cfg)["sd"] is not None
+    with pytest.raises(checkpoint.PretrainedSetError, match="refused by the safe"):
+        checkpoint.load_pretrained(_stub_model(), cfg)
+    cfg.allow_partial_pretrained = True
+    lines = []
+    with warnings.catch_warnings(record=True) as w:
+        warnings.simplefilter("always")
+        m = _stub_model()
+        rep = checkpoint.load_pretrained(m, cfg, log=lines.append)
+    assert rep["sd"] is None and len(rep["refused"]) == 1 and rep["problems"] and m.pretrained_report is rep
+    assert any(issubclass(x.category, RuntimeWarning) for x in w) and any("WARNING" in l for l in lines)
+
+
+def test_partial_pretrained_sets_are_named():
+    from xmask3d_amd import checkpoint
+
+    ok = {"sd": "a", "clip": "b", "tokenizer": "c", "uncond": "x", "refused": []}
+    assert checkpoint.pretrained_problems(ok) == []
+    assert checkpoint.pretrained_problems({"sd": None, "clip": None, "tokenizer": None, "uncond": None, "refused": []}) == []
+    p = checkpoint.pretrained_problems(dict(ok, tokenizer=None))
+    assert len(p) == 1 and "stand-in tokenizer" in p[0] and "tokenizer" in p[0]
+    p = checkpoint.pretrained_problems(dict(ok, sd=None))
+    assert len(p) == 1 and "'sd'" in p[0]

@@ -62,6 +62,9 @@ _SIGS = {
     "xm3d_conv3x3_packed_elems": (ctypes.c_int64, [c_i32, c_i32, c_i32]),
     "xm3d_conv3x3_pack_weight": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_conv3x3_ws_bytes": (ctypes.c_int64, [c_i64, c_i32]),
+    "xm3d_conv3x3_stats_doubles": (ctypes.c_int64, [c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32]),
+    "xm3d_gn_stats_doubles_nchw": (ctypes.c_int64, [c_i64, c_i32, c_i32, c_i32]),
+    "xm3d_gn_stats_doubles_nhwc": (ctypes.c_int64, [c_i64, c_i32, c_i32, c_i32, c_i32]),
     "xm3d_conv3x3_nhwc": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_i32, c_i32,
                                          c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_conv3x3_default_waves": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
@@ -72,6 +75,9 @@ _SIGS = {
     "xm3d_gemm_pack_weight": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_gemm_default_waves": (ctypes.c_int, [c_i64, c_i32, c_i32]),
     "xm3d_gemm_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_i64, c_vp, c_i64, c_i32, c_vp]),
+    "xm3d_conv_gemm_ws_bytes": (ctypes.c_int64, [c_i64, c_i32, c_i32, c_i32]),
+    "xm3d_conv_gemm_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
+                                           c_vp, c_vp]),
     "xm3d_group_norm_nhwc_stats": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_bias_residual_nhwc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "xm3d_attn_mask_bias": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),

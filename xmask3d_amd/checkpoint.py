@@ -149,6 +149,24 @@ def find_pretrained(cfg):
     return {"sd": sd if os.path.isfile(sd) else None, "clip_dir": clip if os.path.isdir(clip) else None, "clip_file": clip_file}
 
 
+class PretrainedSetError(RuntimeError):
+    """the frozen nets' files on disk do not form a usable set (a file was refused by the safe loader, or only part of
+    {SD checkpoint, CLIP weights, tokenizer vocabulary} is there): a run would silently mix released weights with seeded random ones"""
+
+
+def pretrained_problems(rep):
+    """-> list of reasons why the loaded set must not be used silently (empty = a complete, consistent set or nothing at all)"""
+    probs = [f"refused by the safe (tensors-only) loader: {r}" for r in rep["refused"]]
+    have = {k: bool(rep[k]) for k in ("sd", "clip", "tokenizer")}
+    if any(have.values()) and not all(have.values()):
+        missing = [k for k, v in have.items() if not v]
+        loaded = [k for k, v in have.items() if v]
+        probs.append(f"partial set: loaded {loaded}, missing {missing} - "
+                     + ("real CLIP weights would be fed ids of the stand-in tokenizer; " if have["clip"] and not have["tokenizer"] else "")
+                     + "the missing nets keep seeded random weights")
+    return probs
+
+
 def load_pretrained(model, cfg, log=None):
     """Fill the frozen nets of an XMASK3d from local files when they exist (no-op otherwise: seeded random weights and the
     stand-in tokenizer, as every synthetic run uses):
@@ -157,7 +175,8 @@ def load_pretrained(model, cfg, log=None):
       * vocab.json + merges.txt (or open_clip's bpe_simple_vocab_16e6.txt.gz) -> the BPE tokenizer, clip.py:147-149
       * uncond_inputs = text encoder hidden states of "" (ldm.py:105), from the checkpoint's own ``cond_stage_model`` weights when
         it has them, else from the CLIP text tower (Stable Diffusion v1 uses exactly that frozen encoder)
-    -> report dict (what was found and loaded)."""
+    -> report dict (what was found and loaded; ``problems`` lists why the set is unusable).  A refused file or a partial set
+    raises PretrainedSetError unless cfg.allow_partial_pretrained / XM3D_ALLOW_PARTIAL_PRETRAINED=1 (then: RuntimeWarning)."""
     from . import bpe as bpe_mod
     from .clip_model import TextTower
 
@@ -213,7 +232,19 @@ def load_pretrained(model, cfg, log=None):
     model.set_dense_dtype(model.dense_dtype)  # freshly loaded fp32 tensors -> the dense compute dtype
     if any(rep[k] for k in ("sd", "clip", "tokenizer")):
         log(f"pretrained: SD {rep['sd']}, CLIP {rep['clip']}, tokenizer {rep['tokenizer']}, uncond_inputs {rep['uncond']}")
-    for r in rep["refused"]:
-        log(f"pretrained: refused by the safe loader, continuing without it: {r}")
     model.pretrained_report = rep
+    probs = pretrained_problems(rep)
+    rep["problems"] = probs
+    if probs:
+        # refusing an unsafe file is right, carrying on silently is not: scores of released CLIP weights against a random SD UNet
+        # look like a model failure.  Opt out explicitly (cfg.allow_partial_pretrained / XM3D_ALLOW_PARTIAL_PRETRAINED=1) to continue.
+        msg = "pretrained files found but unusable as a set: " + "; ".join(probs)
+        if getattr(cfg, "allow_partial_pretrained", False) or os.environ.get("XM3D_ALLOW_PARTIAL_PRETRAINED", "") == "1":
+            import warnings
+
+            warnings.warn(msg + " (continuing: allow_partial_pretrained)", RuntimeWarning, stacklevel=2)
+            log("pretrained: WARNING " + msg)
+        else:
+            raise PretrainedSetError(msg + ".  Provide the whole set (tensors-only files: a plain state_dict .ckpt / .safetensors), remove the "
+                                     "files, or set cfg.allow_partial_pretrained / XM3D_ALLOW_PARTIAL_PRETRAINED=1")
     return rep

@@ -42,6 +42,19 @@ inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s);
         }                                                                                   \
     } while (0)
 
+// "first call on this device" flag for per-device function attributes (hipFuncSetAttribute(MaxDynamicSharedMemorySize) is per
+// device: a process-wide flag would leave a second GPU of the process unconfigured).  A benign race sets the attribute twice.
+struct DeviceOnce {
+    bool done[64] = {};
+    bool first() {
+        int d = 0;
+        if (hipGetDevice(&d) != hipSuccess || d < 0 || d >= 64) return true;
+        const bool f = !done[d];
+        done[d] = true;
+        return f;
+    }
+};
+
 inline size_t align_up(size_t x, size_t a) { return (x + a - 1) / a * a; }
 
 // carve typed, 256-byte aligned pieces out of a caller-provided workspace

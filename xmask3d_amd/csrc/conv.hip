@@ -62,10 +62,10 @@ struct ConvArgs {
     const float* bias;        // (cout) or (B, cout) with bias_bstride = cout, or null
     const __bf16* residual;   // (B, H, W, cout) or null
     __bf16* out;              // (B, H, W, cout)
-    double* stats_out;        // (B, groups_out, 2) accumulated (+=), or null
+    float2* stats_part;       // per-workgroup (sum, sum of squares) partials [b][cout tile][slot][pixel tile], or null (k_conv_stats_reduce)
     int B, H, W, cin, cout;
     int bias_bstride;
-    int groups_out, cg_out;
+    int groups_out, cg_out, stat_slots;
     int tiles_x, tiles_y, nct;
 };
 
@@ -291,16 +291,15 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a) {
     for (int c = 0; c + 1 < nch; ++c) chunk(c, std::true_type{});
     chunk(nch - 1, std::false_type{});
 
-    // ---- epilogue: + bias (+ residual) -> bf16, GroupNorm statistics of the stored values
-    float* const sred = reinterpret_cast<float*>(smem);  // per-group (sum, sumsq) of this tile
-    const bool want_stats = a.stats_out != nullptr;
+    // ---- epilogue: + bias (+ residual) -> bf16, GroupNorm statistics of the stored values.  No floating-point atomics: every
+    // (wave, channel quad) sum has its own LDS slot, a thread per group adds the group's slots in a fixed order and the workgroup's
+    // partial pair goes to a slot of its own in global memory (k_conv_stats_reduce adds the pixel tiles in fixed order)
+    constexpr int NPH = (NW == 8 && CT == 128) ? 2 : 1;  // waves that share a channel quad (pixel halves of the tile)
+    float2* const sq = reinterpret_cast<float2*>(smem);  // [NPH][CT / 4]; the halo buffers are free: every wave passed the last chunk's barrier
+    const bool want_stats = a.stats_part != nullptr;
     const int cg_out = a.cg_out;
     const int g_first = want_stats ? (ct * CT) / cg_out : 0;
     const int g_last = want_stats ? (min(ct * CT + CT, a.cout) - 1) / cg_out : 0;
-    if (want_stats) {
-        if (tid < 2 * (g_last - g_first + 1)) sred[tid] = 0.f;
-        __syncthreads();
-    }
     const float* const bias = a.bias ? a.bias + int64_t(b) * a.bias_bstride + ct * CT : nullptr;
     if ((CV_ABL & 32) && a.B > 0) {  // timing only: no epilogue (one store keeps the accumulators alive)
         float t = 0.f;
@@ -400,18 +399,50 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a) {
                         s += __shfl_xor(s, off);
                         ss += __shfl_xor(ss, off);
                     }
-                    if (l31 == 0 && live[m]) {
-                        const int gl = (ct * CT + (wb0 + m) * 32 + 16 * h + 4 * q) / cg_out - g_first;
-                        atomicAdd(&sred[2 * gl], s);
-                        atomicAdd(&sred[2 * gl + 1], ss);
-                    }
+                    if (l31 == 0 && live[m]) sq[(NPH == 2 ? (wave & 1) * (CT / 4) : 0) + (wb0 + m) * 8 + 4 * h + q] = make_float2(s, ss);
                 }
         }
     }
     if (want_stats) {
         __syncthreads();
-        if (tid < 2 * (g_last - g_first + 1))
-            atomicAdd(a.stats_out + (int64_t(b) * a.groups_out + g_first) * 2 + tid, double(sred[tid]));
+        if (tid <= g_last - g_first) {
+            const int g = g_first + tid;
+            const int q_lo = (max(g * cg_out, ct * CT) - ct * CT) >> 2, q_hi = (min(min((g + 1) * cg_out, ct * CT + CT), a.cout) - ct * CT) >> 2;
+            float s = 0.f, ss = 0.f;
+#pragma unroll
+            for (int p = 0; p < NPH; ++p)
+                for (int q = q_lo; q < q_hi; ++q) {
+                    const float2 v = sq[p * (CT / 4) + q];
+                    s += v.x;
+                    ss += v.y;
+                }
+            a.stats_part[((int64_t(b) * a.nct + ct) * a.stat_slots + tid) * (a.tiles_x * a.tiles_y) + ty * a.tiles_x + tx] = make_float2(s, ss);
+        }
+    }
+}
+
+// Moments of (image, group) from the per-workgroup partials of the epilogue above: one wave per (image, group); lane i adds pixel
+// tiles i, i + 64, ... of the one or two output-channel tiles the group lies in, in f64, then a fixed shuffle tree
+__global__ __launch_bounds__(64) void k_conv_stats_reduce(const float2* __restrict__ part, int nct, int CT, int slots, int ntiles, int cg, int G,
+                                                          double* __restrict__ stats) {
+    const int b = blockIdx.x / G, g = blockIdx.x % G;
+    const int ct0 = (g * cg) / CT, ct1 = ((g + 1) * cg - 1) / CT;
+    double s = 0.0, ss = 0.0;
+    for (int ct = ct0; ct <= ct1; ++ct) {
+        const float2* p = part + ((int64_t(b) * nct + ct) * slots + (g - (ct * CT) / cg)) * ntiles;
+        for (int i = threadIdx.x; i < ntiles; i += 64) {
+            const float2 v = p[i];
+            s += double(v.x);
+            ss += double(v.y);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        ss += __shfl_xor(ss, off);
+    }
+    if (threadIdx.x == 0) {
+        stats[int64_t(blockIdx.x) * 2] = s;
+        stats[int64_t(blockIdx.x) * 2 + 1] = ss;
     }
 }
 
@@ -504,10 +535,9 @@ __global__ void k_gn_affine(const double* __restrict__ stats, const float* __res
 template <int CT, int MODE, bool UPS, int NW>
 static int launch_conv(const ConvArgs& a, hipStream_t s) {
     using G = ConvGeom<CT, NW>;
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce configured;  // the attribute is per device
+    if (configured.first()) {
         XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3<CT, MODE, UPS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        configured = true;
     }
     const int grid = a.B * a.tiles_y * a.tiles_x * a.nct;
     hipLaunchKernelGGL((k_conv3x3<CT, MODE, UPS, NW>), dim3(grid), dim3(G::NTH), G::LDS, s, a);
@@ -518,10 +548,9 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
 template <int CT, bool UPS, int NW>
 static int launch_conv_f32acc(const ConvArgs& a, hipStream_t s) {
     using G = ConvGeom<CT, NW>;
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce configured;  // the attribute is per device
+    if (configured.first()) {
         XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_f32acc<CT, UPS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
-        configured = true;
     }
     const int grid = a.B * a.tiles_y * a.tiles_x * a.nct;
     hipLaunchKernelGGL((k_conv3x3_f32acc<CT, UPS, NW>), dim3(grid), dim3(G::NTH), G::LDS, s, a);
@@ -536,9 +565,34 @@ static int dispatch_conv(const ConvArgs& a, int gn_act, bool upsample, hipStream
     return upsample ? launch_conv<CT, 0, true, NW>(a, s) : launch_conv<CT, 0, false, NW>(a, s);
 }
 
+// the partial pairs of the statistics epilogue live behind the B * groups * 2 moments in the caller's buffer
+static void conv_stats_setup(ConvArgs& a, double* stats_out, int64_t B, int cout, int cout_tile, int groups_out) {
+    a.stats_part = stats_out ? reinterpret_cast<float2*>(stats_out + B * groups_out * 2) : nullptr;
+    a.groups_out = stats_out ? groups_out : 1;
+    a.cg_out = stats_out ? cout / groups_out : cout;
+    a.stat_slots = stats_out ? cout_tile / a.cg_out + 2 : 0;
+}
+static int conv_stats_finish(const ConvArgs& a, double* stats_out, int cout_tile, hipStream_t s) {
+    if (!stats_out) return XM3D_OK;
+    hipLaunchKernelGGL(k_conv_stats_reduce, dim3(unsigned(a.B * a.groups_out)), dim3(64), 0, s, a.stats_part, a.nct, cout_tile, a.stat_slots,
+                       a.tiles_x * a.tiles_y, a.cg_out, a.groups_out, stats_out);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
 }  // namespace xm3d
 
 using namespace xm3d;
+
+// doubles the `stats_out` buffer of xm3d_conv3x3_nhwc / _f32acc must hold: the B * groups_out * 2 moments (first) + the per-workgroup
+// partial pairs they are reduced from in fixed order (no floating-point atomics: bit-reproducible statistics)
+extern "C" int64_t xm3d_conv3x3_stats_doubles(int64_t B, int32_t H, int32_t W, int32_t cout, int32_t cout_tile, int32_t groups_out, int32_t waves) {
+    if (B <= 0 || H <= 0 || W <= 0 || cout <= 0 || groups_out <= 0 || cout % groups_out != 0 || (cout_tile != 128 && cout_tile != 256)) return 0;
+    if (waves == 0) waves = xm3d_conv3x3_default_waves(H, W, 0, cout);
+    const int TH = waves == 8 ? 8 : 4;
+    const int64_t ntiles = int64_t((H + TH - 1) / TH) * ((W + CV_TW - 1) / CV_TW), nct = (cout + cout_tile - 1) / cout_tile;
+    return B * groups_out * 2 + B * nct * (cout_tile / (cout / groups_out) + 2) * ntiles;
+}
 
 // 256 / 128 when cout is a multiple; other multiples of 32 (UNet: 320) run on 128-channel tiles with a zero-padded last tile
 extern "C" int xm3d_conv3x3_cout_tile(int cout) { return cout <= 0 ? 0 : (cout % 256 == 0 ? 256 : (cout % 32 == 0 ? 128 : 0)); }
@@ -625,21 +679,21 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
     a.bias = bias;
     a.residual = static_cast<const __bf16*>(residual);
     a.out = static_cast<__bf16*>(out);
-    a.stats_out = stats_out;
+    conv_stats_setup(a, stats_out, B, cout, cout_tile, groups_out);
     a.B = int(B);
     a.H = H;
     a.W = W;
     a.cin = cin;
     a.cout = cout;
     a.bias_bstride = bias_bstride;
-    a.groups_out = stats_out ? groups_out : 1;
-    a.cg_out = stats_out ? cout / groups_out : cout;
     a.tiles_x = W / CV_TW;
     a.tiles_y = H / TH;
     a.nct = (cout + cout_tile - 1) / cout_tile;
     const int gn_act = gn ? act : 0;
-    if (cout_tile == 256) return waves == 8 ? dispatch_conv<256, 8>(a, gn_act, upsample != 0, s) : dispatch_conv<256, 4>(a, gn_act, upsample != 0, s);
-    return waves == 8 ? dispatch_conv<128, 8>(a, gn_act, upsample != 0, s) : dispatch_conv<128, 4>(a, gn_act, upsample != 0, s);
+    int rc;
+    if (cout_tile == 256) rc = waves == 8 ? dispatch_conv<256, 8>(a, gn_act, upsample != 0, s) : dispatch_conv<256, 4>(a, gn_act, upsample != 0, s);
+    else rc = waves == 8 ? dispatch_conv<128, 8>(a, gn_act, upsample != 0, s) : dispatch_conv<128, 4>(a, gn_act, upsample != 0, s);
+    return rc != XM3D_OK ? rc : conv_stats_finish(a, stats_out, cout_tile, s);
 }
 
 // ---- f32-accurate convolution from three bf16 passes over split operands:  x = x_hi + x_lo, w = w_hi + w_lo (bf16 each),
@@ -698,19 +752,18 @@ extern "C" int xm3d_conv3x3_nhwc_f32acc(const void* x, int64_t B, int32_t H, int
     a.bias = bias;
     a.residual = reinterpret_cast<const __bf16*>(residual);  // f32 in this variant (the kernel casts back)
     a.out = reinterpret_cast<__bf16*>(out);
-    a.stats_out = stats_out;
+    conv_stats_setup(a, stats_out, B, cout, cout_tile, groups_out);
     a.B = int(B), a.H = H, a.W = W, a.cin = cin, a.cout = cout;
     a.bias_bstride = bias_bstride;
-    a.groups_out = stats_out ? groups_out : 1;
-    a.cg_out = stats_out ? cout / groups_out : cout;
     a.tiles_x = W / CV_TW;
     a.tiles_y = H / TH;
     a.nct = (cout + cout_tile - 1) / cout_tile;
     hipStream_t s = as_stream(stream);
+    int rc;
     if (cout_tile == 256) {
-        if (waves == 8) return upsample ? launch_conv_f32acc<256, true, 8>(a, s) : launch_conv_f32acc<256, false, 8>(a, s);
-        return upsample ? launch_conv_f32acc<256, true, 4>(a, s) : launch_conv_f32acc<256, false, 4>(a, s);
-    }
-    if (waves == 8) return upsample ? launch_conv_f32acc<128, true, 8>(a, s) : launch_conv_f32acc<128, false, 8>(a, s);
-    return upsample ? launch_conv_f32acc<128, true, 4>(a, s) : launch_conv_f32acc<128, false, 4>(a, s);
+        if (waves == 8) rc = upsample ? launch_conv_f32acc<256, true, 8>(a, s) : launch_conv_f32acc<256, false, 8>(a, s);
+        else rc = upsample ? launch_conv_f32acc<256, true, 4>(a, s) : launch_conv_f32acc<256, false, 4>(a, s);
+    } else if (waves == 8) rc = upsample ? launch_conv_f32acc<128, true, 8>(a, s) : launch_conv_f32acc<128, false, 8>(a, s);
+    else rc = upsample ? launch_conv_f32acc<128, true, 4>(a, s) : launch_conv_f32acc<128, false, 4>(a, s);
+    return rc != XM3D_OK ? rc : conv_stats_finish(a, stats_out, cout_tile, s);
 }

@@ -26,6 +26,8 @@
 // Two chunks are unrolled per loop iteration so that ring slots and piece registers are static.
 // Bound: MFMA for K >= 1024 (CLIP, UNet mid levels); HBM for the 320-wide level (2 M K N flop over 2 M (K + N) bytes = 160 flop/B).
 // Algorithmic FLOP = 2 M K N; bytes = M (K + N_out [+ N_out residual]) * 2 + N K * 2.
+#include <stdlib.h>
+
 #include <type_traits>
 
 #include "common.h"
@@ -43,15 +45,26 @@ constexpr int GM_D = 8;                  // weight ring depth in k-steps (= two 
 enum { GM_ACT_NONE = 0, GM_ACT_GELU = 1, GM_ACT_QUICK_GELU = 2, GM_ACT_GEGLU = 3 };
 
 struct GemmArgs {
-    const __bf16* x;         // (M, K), row stride ldx elements
+    const __bf16* x;         // (M, K), row stride ldx elements; GF_CONV: the (B, Hin, Win, Cin) channels-last image
     const __bf16* wp;        // packed weights (xm3d_gemm_pack_weight)
     const float* bias;       // (N) or null; GEGLU: (2 N_out), value half first
-    const __bf16* residual;  // (M, N_out), row stride ldr, or null
-    __bf16* out;             // (M, N_out), row stride ldo
+    const __bf16* residual;  // (M, N_out), row stride ldr, or null (GF_OUT32: f32)
+    __bf16* out;             // (M, N_out), row stride ldo (GF_OUT32: f32; split-K: slab blockIdx.y at + blockIdx.y * M * ldo)
+    const float* accin;      // GF_OUT32: (M, N_out) f32, row stride ldo, added BEFORE the activation (accumulating passes), or null
     int M, K, N;             // N = rows of W (GEGLU: 2 N_out)
     int ldx, ldr, ldo;
     int nct;                 // column tiles
+    int chunks_per_split;    // K chunks per blockIdx.y slice (split-K; = K / KC without)
+    // GF_CONV: row m = output pixel (b, oy, ox) of a (ksz x ksz, stride, zero padding) convolution, K = ksz * ksz * Cin in (ky, kx, c) order
+    int Hin, Win, Cin, Ho, Wo, stride, pad_t, pad_l, ksz;
 };
+
+// FL bits.  GF_CONV: implicit-GEMM convolution - the token rows are gathered from the image while they are staged (no im2col tensor):
+// strided / small-map / 1x1 convolutions that conv.hip's 32-pixel-wide halo tiles do not take.  GF_OUT32: f32 output (accumulating
+// passes of the f32-accurate GEMM, partial slabs of the deterministic split-K).  GF_F16: operands are IEEE half (v_mfma_f32_32x32x16_f16):
+// the two-term split of an f32 operand in halves carries 22 mantissa bits (bf16: 16)
+enum { GF_CONV = 1, GF_OUT32 = 2, GF_F16 = 4 };
+typedef _Float16 gm_f16x8 __attribute__((ext_vector_type(8)));
 
 // GELU(x) = x/2 (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, two hardware transcendentals)
 // instead of erff's branchy polynomial: the epilogue of a GEGLU tile evaluates it 128 times per lane
@@ -66,9 +79,11 @@ __device__ __forceinline__ float gm_gelu(float x) {
 // NW = 8: 512 threads, 256 token rows (one workgroup per CU).  NW = 4 (CT = 128 only): 256 threads, 128 token rows, a wave = one
 // 32-column block x all 128 rows; two to three workgroups per CU - the geometry for small M (M = 5 k rows x 256-row tiles leaves
 // the chip two thirds empty) and for overlapping one workgroup's prologue / epilogue with another's K loop
-template <int CT, int ACT, int KC, int NW>
+template <int CT, int ACT, int KC, int NW, int FL>
 __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     static_assert(NW == 8 || (NW == 4 && CT == 128), "geometries");
+    constexpr bool CONV = (FL & GF_CONV) != 0, OUT32 = (FL & GF_OUT32) != 0, F16 = (FL & GF_F16) != 0;
+    static_assert(!OUT32 || ACT != GM_ACT_GEGLU, "GEGLU has no f32-output form");
     constexpr int MT = NW * 32;            // token rows per workgroup
     constexpr int NTH = NW * 64;
     constexpr int NT = CT == 256 ? 8 : 4;  // 32-token tiles per wave
@@ -93,14 +108,16 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     }
     const int ct = bid % a.nct, mt = bid / a.nct;
     const int row0 = mt * MT, M = a.M;
-    const int nch = a.K / KC, nk = nch * KS;
+    // split-K: slice blockIdx.y owns chunks [cfirst, cfirst + nch) of the K loop (the host makes every slice non-empty)
+    const int cfirst = blockIdx.y * a.chunks_per_split;
+    const int nch = min(a.chunks_per_split, a.K / KC - cfirst), nk = nch * KS;
     // N that is not a multiple of the column tile (UNet: 320, 960 with CT = 128): the row blocks past N in the last tile belong to
     // waves that only stage tokens - no weight stream, no fragment reads, no MFMAs (their SIMD's other wave runs alone)
     const int gblk = ct * (CT / 32) + wb;  // global 32-row block of W
     const bool active = gblk * 32 < a.N;
 
     // ---- weight stream of this wave: 1 KiB (64 lanes x 16 bytes = one A fragment) per k-step, contiguous
-    const char* const wstream = reinterpret_cast<const char*>(a.wp) + (int64_t(ct) * (CT / 32) + wb) * nk * 1024 + lane * 16;
+    const char* const wstream = reinterpret_cast<const char*>(a.wp) + ((int64_t(ct) * (CT / 32) + wb) * (a.K / 16) + int64_t(cfirst) * KS) * 1024 + lane * 16;
     gm_bf16x8 wr[D];
 #pragma unroll
     for (int i = 0; i < D; ++i) wr[i] = *reinterpret_cast<const gm_bf16x8*>(wstream + int64_t(i < nk ? i : nk - 1) * 1024);
@@ -109,16 +126,66 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     // Rows past M read row M - 1 (their results are never stored).  ONE register per piece: piece r of chunk c + 1 is written to LDS
     // in k-step r of chunk c and the register is re-requested right there for chunk c + 2 - every load has a whole chunk to land
     const int kc = tid % (KC / 8), prow = tid / (KC / 8);
-    unsigned aoff[KS];  // element offsets (32 bit: the host checks M * ldx < 2^31)
+    int aoff[KS];       // element offsets (32 bit: the host checks the extent); GF_CONV: of the pixel under tap (0, 0), may be negative
+    unsigned vmask[KS];  // GF_CONV: bit ky: input row oy * stride - pad_t + ky is inside the image; bit 4 + kx: the same for columns
 #pragma unroll
     for (int r = 0; r < KS; ++r) {
         const int row = row0 + prow + RPR * r;
-        aoff[r] = unsigned(row < M ? row : M - 1) * unsigned(a.ldx) + kc * 8;
+        const int rc = row < M ? row : M - 1;
+        if constexpr (CONV) {
+            const int ox = rc % a.Wo, t = rc / a.Wo, oy = t % a.Ho, b = t / a.Ho;
+            const int iy0 = oy * a.stride - a.pad_t, ix0 = ox * a.stride - a.pad_l;
+            aoff[r] = ((b * a.Hin + iy0) * a.Win + ix0) * a.Cin + kc * 8;
+            unsigned m = 0;
+            for (int k = 0; k < a.ksz; ++k) {
+                m |= unsigned(iy0 + k >= 0 && iy0 + k < a.Hin) << k;
+                m |= unsigned(ix0 + k >= 0 && ix0 + k < a.Win) << (4 + k);
+            }
+            vmask[r] = m;
+        } else {
+            aoff[r] = int(unsigned(rc) * unsigned(a.ldx)) + kc * 8;
+            vmask[r] = 0;
+        }
     }
     char* const a_wr = smem + prow * PSTR + kc * 16;  // + r * RPR * PSTR + buffer
     gm_u32x4 raw[KS];
+    // GF_CONV: chunk -> (filter tap, channel slice), walked incrementally (wave-uniform): `ld` is the chunk being requested, `wr_need`
+    // the validity bits of the chunk whose pieces are being written to LDS (requested one chunk earlier)
+    const int cpt = CONV ? a.Cin / KC : 1;  // chunks per tap
+    struct Tap {
+        int sl, kx, ky, off;
+        unsigned need;
+    };
+    Tap ld;
+    unsigned wr_need = 0;
+    auto tap_set = [&](Tap& t, int cabs) __attribute__((always_inline)) {
+        const int tap = cabs / cpt;
+        t.sl = cabs - tap * cpt;
+        t.ky = tap / a.ksz;
+        t.kx = tap - t.ky * a.ksz;
+        t.off = (t.ky * a.Win + t.kx) * a.Cin + t.sl * KC;
+        t.need = (1u << t.ky) | (16u << t.kx);
+    };
+    auto tap_next = [&](Tap& t) __attribute__((always_inline)) {
+        if (++t.sl == cpt) {
+            t.sl = 0;
+            if (++t.kx == a.ksz) t.kx = 0, ++t.ky;
+        }
+        t.off = (t.ky * a.Win + t.kx) * a.Cin + t.sl * KC;
+        t.need = (1u << t.ky) | (16u << t.kx);
+    };
+    // request piece r of the chunk `ld` points at (plain: of local chunk c, clamped to the slice's last)
     auto a_load = [&](int r, int c) __attribute__((always_inline)) {
-        raw[r] = *reinterpret_cast<const gm_u32x4*>(a.x + aoff[r] + (c < nch ? c : nch - 1) * KC);
+        if constexpr (CONV) {
+            const bool ok = (vmask[r] & ld.need) == ld.need;
+            raw[r] = *reinterpret_cast<const gm_u32x4*>(a.x + (ok ? aoff[r] + ld.off : kc * 8));
+        } else {
+            raw[r] = *reinterpret_cast<const gm_u32x4*>(a.x + aoff[r] + (cfirst + (c < nch ? c : nch - 1)) * KC);
+        }
+    };
+    auto a_piece = [&](int r) __attribute__((always_inline)) -> gm_u32x4 {  // zero padding: a piece under a tap outside the image
+        if constexpr (CONV) return (vmask[r] & wr_need) == wr_need ? raw[r] : gm_u32x4{0u, 0u, 0u, 0u};
+        else return raw[r];
     };
 
     // tokens as B operand: row (nbase + n) * 32 + l31 of the tile, 16-byte granule 2 ks + h
@@ -131,10 +198,15 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
         for (int i = 0; i < 16; ++i) acc[n][i] = 0.f;
 
     // ---- prologue: chunk 0 into buffer 0, chunk 1 requested
+    if constexpr (CONV) tap_set(ld, cfirst);
 #pragma unroll
     for (int r = 0; r < KS; ++r) a_load(r, 0);
+    wr_need = ld.need;
 #pragma unroll
-    for (int r = 0; r < KS; ++r) *reinterpret_cast<gm_u32x4*>(a_wr + r * RPR * PSTR) = raw[r];
+    for (int r = 0; r < KS; ++r) *reinterpret_cast<gm_u32x4*>(a_wr + r * RPR * PSTR) = a_piece(r);
+    if constexpr (CONV) {
+        if (nch > 1) tap_next(ld);
+    }
 #pragma unroll
     for (int r = 0; r < KS; ++r) a_load(r, 1);
     __syncthreads();
@@ -146,6 +218,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
         constexpr bool ACTV = decltype(act_tag)::value;  // a wave past N only stages (one branch per chunk, straight-line bodies)
         const char* const xl = xbase + P * ASZ;
         char* const anext = a_wr + (1 - P) * ASZ;
+        if constexpr (CONV) {  // the pieces in flight belong to chunk c + 1 (written in this chunk); requests go to chunk c + 2
+            wr_need = ld.need;
+            if (c + 2 < nch) tap_next(ld);
+        }
         gm_bf16x8 xf[2][4];
         constexpr int XS = KS * NG;  // x-sets (4 token tiles each) per chunk
         auto x_load = [&](int xs, int s) __attribute__((always_inline)) {
@@ -162,13 +238,17 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
             if (ACTV && g + 1 < XS) x_load(g + 1, (g + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
             if (half == 0) {
-                *reinterpret_cast<gm_u32x4*>(anext + ks * RPR * PSTR) = raw[ks];
+                *reinterpret_cast<gm_u32x4*>(anext + ks * RPR * PSTR) = a_piece(ks);
                 a_load(ks, c + 2);
             }
             if (ACTV) {
 #pragma unroll
-                for (int n = 0; n < 4; ++n)
-                    acc[half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[slot], xf[g & 1][n], acc[half * 4 + n], 0, 0, 0);
+                for (int n = 0; n < 4; ++n) {
+                    if constexpr (F16)
+                        acc[half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gm_f16x8, wr[slot]), __builtin_bit_cast(gm_f16x8, xf[g & 1][n]),
+                                                                                   acc[half * 4 + n], 0, 0, 0);
+                    else acc[half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[slot], xf[g & 1][n], acc[half * 4 + n], 0, 0, 0);
+                }
                 if (half == NG - 1) {  // the ring slot is free: request the fragment of k-step + D
                     __builtin_amdgcn_sched_barrier(0);
                     const int jn = c * KS + ks + D;
@@ -230,6 +310,40 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
                     pk[i] = (__bf16)(val * gm_gelu(gate) + res);
                 }
                 if (row < M) *reinterpret_cast<gm_bf16x8*>(a.out + int64_t(row) * a.ldo + col) = pk;
+            }
+        }
+    } else if constexpr (OUT32) {
+        // f32 rows: out = act(acc + bias + accin) + residual; split-K slices write their own slab (no bias / accin / residual there)
+        const int col = gblk * 32 + 16 * h;
+        if (active) {
+            float* const outf = reinterpret_cast<float*>(a.out) + int64_t(blockIdx.y) * a.M * a.ldo;
+            const float* const resf = reinterpret_cast<const float*>(a.residual);
+            float4 bq[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bq[q] = a.bias ? *reinterpret_cast<const float4*>(a.bias + col + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+            for (int n = 0; n < NT; ++n) {
+                const int row = row0 + (nbase + n) * 32 + l31;
+                if (row >= M) continue;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v[4] = {acc[n][4 * q] + bq[q].x, acc[n][4 * q + 1] + bq[q].y, acc[n][4 * q + 2] + bq[q].z, acc[n][4 * q + 3] + bq[q].w};
+                    if (a.accin) {
+                        const float4 t = *reinterpret_cast<const float4*>(a.accin + int64_t(row) * a.ldo + col + 4 * q);
+                        v[0] += t.x, v[1] += t.y, v[2] += t.z, v[3] += t.w;
+                    }
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if constexpr (ACT == GM_ACT_GELU) v[j] = gm_gelu(v[j]);
+                        if constexpr (ACT == GM_ACT_QUICK_GELU)
+                            v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[j]));
+                    }
+                    if (resf) {
+                        const float4 t = *reinterpret_cast<const float4*>(resf + int64_t(row) * a.ldr + col + 4 * q);
+                        v[0] += t.x, v[1] += t.y, v[2] += t.z, v[3] += t.w;
+                    }
+                    *reinterpret_cast<float4*>(outf + int64_t(row) * a.ldo + col + 4 * q) = make_float4(v[0], v[1], v[2], v[3]);
+                }
             }
         }
     } else {
@@ -304,39 +418,82 @@ __global__ void k_gemm_pack(const T* __restrict__ w, int N, int K, int nblk, int
     reinterpret_cast<gm_bf16x8*>(out)[i] = o;
 }
 
-template <int CT, int ACT, int KC, int NW>
-static int launch_gemm_kc(const GemmArgs& a, hipStream_t s) {
+// out = act(sum_z slab[z] + bias) + residual, bf16 rows: the deterministic split-K's second launch (slices summed in index order)
+__global__ void k_gemm_splitk_finish(const float* __restrict__ slab, int ksplit, int64_t M, int N, const float* __restrict__ bias, int act,
+                                     const __bf16* __restrict__ residual, int64_t ldr, __bf16* __restrict__ out, int64_t ldo) {
+    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;  // one 8-column vector
+    const int n8 = N / 8;
+    if (i >= M * n8) return;
+    const int64_t row = i / n8;
+    const int col = int(i - row * n8) * 8;
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = bias ? bias[col + j] : 0.f;
+    for (int z = 0; z < ksplit; ++z) {
+        const float* p = slab + (int64_t(z) * M + row) * N + col;
+        const float4 t0 = *reinterpret_cast<const float4*>(p), t1 = *reinterpret_cast<const float4*>(p + 4);
+        v[0] += t0.x, v[1] += t0.y, v[2] += t0.z, v[3] += t0.w, v[4] += t1.x, v[5] += t1.y, v[6] += t1.z, v[7] += t1.w;
+    }
+    gm_bf16x8 r8;
+    if (residual) r8 = *reinterpret_cast<const gm_bf16x8*>(residual + row * ldr + col);
+    gm_bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        float t = v[j];
+        if (act == GM_ACT_GELU) t = gm_gelu(t);
+        else if (act == GM_ACT_QUICK_GELU) t = t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * t));
+        if (residual) t += float(r8[j]);
+        o[j] = (__bf16)t;
+    }
+    *reinterpret_cast<gm_bf16x8*>(out + row * ldo + col) = o;
+}
+
+template <int CT, int ACT, int KC, int NW, int FL>
+static int launch_gemm_kc(const GemmArgs& a0, int ksplit, hipStream_t s) {
     constexpr int MT = NW * 32;
     constexpr int LDS = 2 * MT * (KC * 2 + 16);
-    static bool configured = false;
-    if (!configured) {
-        XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<CT, ACT, KC, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
-        configured = true;
+    static DeviceOnce configured;  // the attribute is per device
+    if (configured.first()) {
+        XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<CT, ACT, KC, NW, FL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
     }
+    GemmArgs a = a0;
+    const int nch = a.K / KC;
+    a.chunks_per_split = (nch + ksplit - 1) / ksplit;
+    const int slices = (nch + a.chunks_per_split - 1) / a.chunks_per_split;  // every slice non-empty
     const int grid = ((a.M + MT - 1) / MT) * a.nct;
-    hipLaunchKernelGGL((k_gemm<CT, ACT, KC, NW>), dim3(grid), dim3(NW * 64), LDS, s, a);
+    hipLaunchKernelGGL((k_gemm<CT, ACT, KC, NW, FL>), dim3(grid, slices), dim3(NW * 64), LDS, s, a);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
 
-// 128-channel chunks (one barrier per 8 k-steps) whenever K allows; K = 320 and other odd multiples of 64 run 64-channel chunks.
-// waves: 8 / 4 (4: CT = 128 only)
-template <int CT, int ACT>
-static int launch_gemm(const GemmArgs& a, int waves, hipStream_t s) {
+// 128-channel chunks (one barrier per 8 k-steps) whenever K (GF_CONV: Cin) allows; K = 320 and other odd multiples of 64 run 64-channel
+// chunks.  waves: 8 / 4 (4: CT = 128 only)
+template <int CT, int ACT, int FL>
+static int launch_gemm(const GemmArgs& a, int waves, int ksplit, hipStream_t s) {
+    const bool kc128 = ((FL & GF_CONV) ? a.Cin : a.K) % 128 == 0;
     if constexpr (CT == 128) {
-        if (waves == 4) return a.K % 128 == 0 ? launch_gemm_kc<CT, ACT, 128, 4>(a, s) : launch_gemm_kc<CT, ACT, 64, 4>(a, s);
+        if (waves == 4) return kc128 ? launch_gemm_kc<CT, ACT, 128, 4, FL>(a, ksplit, s) : launch_gemm_kc<CT, ACT, 64, 4, FL>(a, ksplit, s);
     }
-    return a.K % 128 == 0 ? launch_gemm_kc<CT, ACT, 128, 8>(a, s) : launch_gemm_kc<CT, ACT, 64, 8>(a, s);
+    return kc128 ? launch_gemm_kc<CT, ACT, 128, 8, FL>(a, ksplit, s) : launch_gemm_kc<CT, ACT, 64, 8, FL>(a, ksplit, s);
 }
 
 template <int CT>
 static int dispatch_gemm(const GemmArgs& a, int act, int waves, hipStream_t s) {
     switch (act) {
-        case GM_ACT_NONE: return launch_gemm<CT, GM_ACT_NONE>(a, waves, s);
-        case GM_ACT_GELU: return launch_gemm<CT, GM_ACT_GELU>(a, waves, s);
-        case GM_ACT_QUICK_GELU: return launch_gemm<CT, GM_ACT_QUICK_GELU>(a, waves, s);
-        default: return launch_gemm<CT, GM_ACT_GEGLU>(a, waves, s);
+        case GM_ACT_NONE: return launch_gemm<CT, GM_ACT_NONE, 0>(a, waves, 1, s);
+        case GM_ACT_GELU: return launch_gemm<CT, GM_ACT_GELU, 0>(a, waves, 1, s);
+        case GM_ACT_QUICK_GELU: return launch_gemm<CT, GM_ACT_QUICK_GELU, 0>(a, waves, 1, s);
+        default: return launch_gemm<CT, GM_ACT_GEGLU, 0>(a, waves, 1, s);
     }
+}
+
+// number of K slices of the deterministic split-K.  Measured (tools/conv_gemm_bench.py SWEEP=1, 20 views, profiles/r04_conv_gemm_bench.log):
+// the slab round trip + second launch only pay when the grid has far fewer tiles than the chip has CUs AND K is long - the 8^2 UNet
+// level (100 tiles of 128 x 128, K = 11520 / 23040: 63 vs 89 us, 110 vs 176 us with 2 - 4 slices); at 200 - 400 tiles one slice wins
+// (unet res 1280 @16: 177 vs 205 us; 1x1 1280 @16: 28 vs 59 us)
+static int choose_ksplit(int64_t tiles, int K) {
+    if (tiles > 128 || K < 4096) return 1;
+    return tiles > 64 ? 2 : 4;
 }
 
 }  // namespace xm3d
@@ -402,11 +559,81 @@ extern "C" int xm3d_gemm_bf16(const void* x, int64_t M, int K, int64_t ldx, cons
     a.bias = bias;
     a.residual = static_cast<const __bf16*>(residual);
     a.out = static_cast<__bf16*>(out);
+    a.accin = nullptr;
     a.M = int(M), a.K = K, a.N = N;
     a.ldx = int(ldx), a.ldr = int(ldr), a.ldo = int(ldo);
     a.nct = (N + col_tile - 1) / col_tile;
+    a.Hin = a.Win = a.Cin = a.Ho = a.Wo = a.stride = a.pad_t = a.pad_l = a.ksz = 0;
     XM3D_REQUIRE(((M + 127) / 128) * a.nct < (int64_t(1) << 31), "gemm_bf16: grid too large");
     XM3D_REQUIRE(waves == 0 || waves == 8 || (waves == 4 && col_tile == 128), "gemm_bf16: waves must be 0 (choose), 8, or 4 with column tile 128");
     if (waves == 0) waves = xm3d_gemm_default_waves(M, N, col_tile);
     return col_tile == 256 ? dispatch_gemm<256>(a, act, waves, as_stream(stream)) : dispatch_gemm<128>(a, act, waves, as_stream(stream));
+}
+
+// ---- implicit-GEMM convolution (GF_CONV): out (B, Ho, Wo, N) = conv(x (B, Hin, Win, Cin), W) + bias (+ residual), channels-last bf16, for the
+// convolutions conv.hip's 32-pixel-wide halo tiles do not take - strided Downsample, the 16^2 / 8^2 UNet levels, 1x1 with large K.
+// Small grids run a DETERMINISTIC split-K: K slices write f32 partial slabs, a second launch adds them in slice order (the library's
+// split-K convolutions add with atomics: the only irreproducible kernels the forward had, tools/find_nondeterminism.py).
+static void conv_gemm_plan(int64_t M, int N, int K, int col_tile, int* tile, int* waves, int* ksplit) {
+    int t = col_tile;
+    if (t == 256 && ((M + 255) / 256) * ((N + 255) / 256) < 200) t = 128;
+    const int w = t == 128 ? xm3d_gemm_default_waves(M, N, 128) : 8;
+    const int64_t tiles = ((M + w * 32 - 1) / (w * 32)) * ((N + t - 1) / t);
+    *tile = t, *waves = w, *ksplit = choose_ksplit(tiles, K);
+    if (const char* e = getenv("XM3D_CONV_GEMM_KSPLIT")) {  // tuning aid (tools/conv_gemm_bench.py): force the number of K slices
+        const int f = atoi(e);
+        if (f >= 1 && f <= 64 && K / f >= 64) *ksplit = f;
+    }
+}
+
+extern "C" int64_t xm3d_conv_gemm_ws_bytes(int64_t M, int32_t N, int32_t K, int32_t col_tile) {
+    if (M <= 0 || N <= 0 || K <= 0 || (col_tile != 128 && col_tile != 256)) return 0;
+    int t, w, ks;
+    conv_gemm_plan(M, N, K, col_tile, &t, &w, &ks);
+    return ks > 1 ? int64_t(ks) * M * N * int64_t(sizeof(float)) : 0;
+}
+
+extern "C" int xm3d_conv_gemm_bf16(const void* x, int64_t B, int32_t Hin, int32_t Win, int32_t Cin, const void* wpacked, int32_t N, int32_t col_tile,
+                                   int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, const float* bias,
+                                   const void* residual, void* out, void* ws, void* stream) {
+    XM3D_REQUIRE(x && wpacked && out, "conv_gemm_bf16: null pointer");
+    XM3D_REQUIRE(B > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cin % GM_KC == 0, "conv_gemm_bf16: bad shape (Cin %d must be a multiple of %d)", Cin, GM_KC);
+    XM3D_REQUIRE(ksize >= 1 && ksize <= 3 && stride >= 1 && pad_t >= 0 && pad_l >= 0 && pad_t < ksize && pad_l < ksize, "conv_gemm_bf16: kernel size 1..3, padding < kernel size");
+    XM3D_REQUIRE((Ho - 1) * stride - pad_t < Hin && (Wo - 1) * stride - pad_l < Win, "conv_gemm_bf16: output %dx%d reaches outside the input", Ho, Wo);
+    XM3D_REQUIRE(col_tile == 128 || col_tile == 256, "conv_gemm_bf16: column tile %d unsupported", col_tile);
+    XM3D_REQUIRE(N > 0 && N % 32 == 0, "conv_gemm_bf16: N %d is not a multiple of 32", N);
+    const int64_t M = B * Ho * Wo;
+    XM3D_REQUIRE(M < (int64_t(1) << 31) - GM_MT && B * Hin * Win * Cin < (int64_t(1) << 31) && M * N < (int64_t(1) << 31), "conv_gemm_bf16: tensor too large for 32-bit offsets");
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(out) |
+                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(bias) | reinterpret_cast<uintptr_t>(ws)) & 15) == 0,
+                 "conv_gemm_bf16: tensors must be 16-byte aligned");
+    GemmArgs a;
+    a.x = static_cast<const __bf16*>(x);
+    a.wp = static_cast<const __bf16*>(wpacked);
+    a.accin = nullptr;
+    a.M = int(M), a.K = ksize * ksize * Cin, a.N = N;
+    a.ldx = 0, a.ldr = N, a.ldo = N;
+    a.Hin = Hin, a.Win = Win, a.Cin = Cin, a.Ho = Ho, a.Wo = Wo, a.stride = stride, a.pad_t = pad_t, a.pad_l = pad_l, a.ksz = ksize;
+    int tile, waves, ksplit;
+    conv_gemm_plan(M, N, a.K, col_tile, &tile, &waves, &ksplit);
+    a.nct = (N + tile - 1) / tile;
+    hipStream_t s = as_stream(stream);
+    if (ksplit == 1) {
+        a.bias = bias;
+        a.residual = static_cast<const __bf16*>(residual);
+        a.out = static_cast<__bf16*>(out);
+        return tile == 256 ? launch_gemm<256, GM_ACT_NONE, GF_CONV>(a, waves, 1, s) : launch_gemm<128, GM_ACT_NONE, GF_CONV>(a, waves, 1, s);
+    }
+    XM3D_REQUIRE(ws, "conv_gemm_bf16: this shape runs split-K and needs xm3d_conv_gemm_ws_bytes(M, N, K, col_tile) bytes of workspace");
+    a.bias = nullptr;
+    a.residual = nullptr;
+    a.out = static_cast<__bf16*>(ws);
+    const int rc = tile == 256 ? launch_gemm<256, GM_ACT_NONE, GF_CONV | GF_OUT32>(a, waves, ksplit, s) : launch_gemm<128, GM_ACT_NONE, GF_CONV | GF_OUT32>(a, waves, ksplit, s);
+    if (rc != XM3D_OK) return rc;
+    const int KC = a.Cin % 128 == 0 ? 128 : 64, nch = a.K / KC, cps = (nch + ksplit - 1) / ksplit, slices = (nch + cps - 1) / cps;
+    const int64_t nvec = M * (N / 8);
+    hipLaunchKernelGGL(k_gemm_splitk_finish, dim3(unsigned((nvec + 255) / 256)), dim3(256), 0, s, static_cast<const float*>(ws), slices, M, N, bias, 0,
+                       static_cast<const __bf16*>(residual), int64_t(N), static_cast<__bf16*>(out), int64_t(N));
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
 }

@@ -4,7 +4,9 @@
 // ldm's ResnetBlock / ResBlock / SpatialTransformer, reached from models/modeling/meta_arch/ldm.py:386-490) by two
 // HBM-streaming passes:
 //   k_gn_stats : each workgroup reduces one <=16 Ki-element slice of one (sample, group) - contiguous in NCHW -
-//                with 16-byte loads, f32 lanes -> f64 wave/LDS reduction -> one f64 atomic pair per workgroup
+//                with 16-byte loads, f32 lanes -> f64 wave/LDS reduction -> one partial pair per workgroup in its own slot;
+//                k_gn_reduce sums the slots of a (sample, group) in FIXED order (no floating-point atomics anywhere: two runs
+//                on the same input give the same bits, which the sharded == single-process inference test relies on)
 //   k_gn_apply : y = act((x - mean) * rstd * gamma[c] + beta[c]), act = none | SiLU (1) | ReLU (2), 16 bytes per lane, the second read of x
 //                mostly hits L2 / Infinity Cache for all but the 512x512 VAE maps
 // Algorithmic bytes: 3 * numel * sizeof(T) (two reads, one write).
@@ -17,16 +19,30 @@ namespace xm3d {
 
 constexpr int GN_SLICE = 16384;  // elements per workgroup in the statistics pass
 
-// zeroing by kernel, not hipMemsetAsync: memset nodes captured into a HIP graph were observed not to take effect on
-// replay with this ROCm (stale statistics -> NaN), a kernel node always does
-__global__ void k_gn_zero(double* __restrict__ p, int n) {
-    const int i = blockIdx.x * blockDim.x + threadIdx.x;
-    if (i < n) p[i] = 0.0;
+// Moments of a (sample, group) from the per-workgroup partial pairs: one wave per (sample, group), lane i takes partials
+// i, i + 64, ... in f64, then a fixed shuffle tree.  part is [(b * G + g)][n_part] float2 (sum, sum of squares).
+__global__ __launch_bounds__(64) void k_gn_reduce(const float2* __restrict__ part, int n_part, double* __restrict__ stats) {
+    const int64_t bg = blockIdx.x;
+    const float2* p = part + bg * n_part;
+    double s = 0.0, ss = 0.0;
+    for (int i = threadIdx.x; i < n_part; i += 64) {
+        const float2 v = p[i];
+        s += double(v.x);
+        ss += double(v.y);
+    }
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        ss += __shfl_xor(ss, off);
+    }
+    if (threadIdx.x == 0) {
+        stats[bg * 2] = s;
+        stats[bg * 2 + 1] = ss;
+    }
 }
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_gn_stats(const T* __restrict__ x, int64_t group_elems, int slices,
-                                                  double* __restrict__ stats) {
+                                                  float2* __restrict__ part) {
     constexpr int N = VecIO<T>::N;
     const int64_t bg = blockIdx.x / slices;
     const int slice = blockIdx.x % slices;
@@ -55,10 +71,7 @@ __global__ __launch_bounds__(256) void k_gn_stats(const T* __restrict__ x, int64
         sm[wave * 2 + 1] = dss;
     }
     __syncthreads();
-    if (threadIdx.x == 0) {
-        atomicAdd(&stats[bg * 2], sm[0] + sm[2] + sm[4] + sm[6]);
-        atomicAdd(&stats[bg * 2 + 1], sm[1] + sm[3] + sm[5] + sm[7]);
-    }
+    if (threadIdx.x == 0) part[bg * slices + slice] = make_float2(float(sm[0] + sm[2] + sm[4] + sm[6]), float(sm[1] + sm[3] + sm[5] + sm[7]));
 }
 
 template <typename T>
@@ -94,17 +107,39 @@ __global__ __launch_bounds__(256) void k_gn_apply(const T* __restrict__ x, const
 // ---------------------------------------------------------------- NHWC (channels-last) variants
 // x is (B, HW, C): a pixel's C channels are contiguous, so a 16-byte vector holds N consecutive channels of one pixel.
 // Statistics: a workgroup owns a slab of pixels of one sample; thread t owns vector column (t % VPP) and walks pixels with
-// stride (256 / VPP); per-element f32 partials are folded per group into LDS (f32 atomics), then one f64 atomic pair per
-// (workgroup, group).  Apply: per element group lookup (a vector may straddle two groups when C/G < N).
+// stride (256 / VPP); the per-channel f32 sums of every thread go to their own LDS slot, are folded per group in a fixed order
+// (gn_fold_store) and leave as ONE partial pair per (workgroup, group) in a slot of its own; k_gn_reduce sums a group's slots
+// in fixed order.  Apply: per element group lookup (a vector may straddle two groups when C/G < N).
+
+// red: [pixel lane][C] (sum, sum of squares) of this workgroup.  Thread t serves group t / hpg as helper t % hpg (hpg = a power of
+// two <= 64 helpers per group, hpg * G <= 256): items helper, helper + hpg, ... of the group's lanes * cg slots, then a shuffle
+// tree over the helpers - the order of the additions depends on nothing but the shape.
+__device__ __forceinline__ void gn_fold_store(const float2* red, int lanes, int C, int cg, int G, int hpg, float2* __restrict__ part,
+                                               int64_t b, int slabs, int slab) {
+    const int g = threadIdx.x / hpg, hl = threadIdx.x % hpg;
+    float s = 0.f, ss = 0.f;
+    if (g < G) {
+        const int items = lanes * cg;
+        for (int i = hl; i < items; i += hpg) {
+            const int pl = i / cg;
+            const float2 v = red[pl * C + g * cg + (i - pl * cg)];
+            s += v.x;
+            ss += v.y;
+        }
+    }
+    for (int off = hpg >> 1; off > 0; off >>= 1) {
+        s += __shfl_xor(s, off);
+        ss += __shfl_xor(ss, off);
+    }
+    if (g < G && hl == 0) part[(b * G + g) * slabs + slab] = make_float2(s, ss);
+}
 
 template <typename T>
 __global__ __launch_bounds__(256) void k_gn_stats_nhwc(const T* __restrict__ x, const T* __restrict__ shift, int shift_bstride, int hw, int C, int cg, int G, int slabs, int pix,
-                                                       double* __restrict__ stats) {
+                                                       int hpg, float2* __restrict__ part) {
     constexpr int N = VecIO<T>::N;
-    __shared__ float sm[2 * 64];  // G <= 64
+    extern __shared__ __attribute__((aligned(16))) float2 gn_red[];  // [pixel lane][C]
     const int b = blockIdx.x / slabs, slab = blockIdx.x % slabs;
-    if (threadIdx.x < 2 * G) sm[threadIdx.x] = 0.f;
-    __syncthreads();
     const int vpp = C / N;                         // vectors per pixel
     const int p0 = slab * pix;
     const int p1 = (p0 + pix < hw) ? p0 + pix : hw;
@@ -141,28 +176,11 @@ __global__ __launch_bounds__(256) void k_gn_stats_nhwc(const T* __restrict__ x, 
                 ss[j] = fmaf(val[j], val[j], ss[j]);
             }
         }
-        int gprev = (v * N) / cg;
-        float as = 0.f, ass = 0.f;
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const int g = (v * N + j) / cg;
-            if (g != gprev) {
-                atomicAdd(&sm[2 * gprev], as);
-                atomicAdd(&sm[2 * gprev + 1], ass);
-                as = ass = 0.f;
-                gprev = g;
-            }
-            as += s[j];
-            ass += ss[j];
-        }
-        atomicAdd(&sm[2 * gprev], as);
-        atomicAdd(&sm[2 * gprev + 1], ass);
+        for (int j = 0; j < N; ++j) gn_red[pl * C + v * N + j] = make_float2(s[j], ss[j]);
     }
     __syncthreads();
-    if (threadIdx.x < G) {
-        atomicAdd(&stats[(int64_t(b) * G + threadIdx.x) * 2], double(sm[2 * threadIdx.x]));
-        atomicAdd(&stats[(int64_t(b) * G + threadIdx.x) * 2 + 1], double(sm[2 * threadIdx.x + 1]));
-    }
+    gn_fold_store(gn_red, vpp < 256 ? 256 / vpp : 1, C, cg, G, hpg, part, b, slabs, slab);
 }
 
 // out = a + b + bias[c] (the residual add that closes a ResBlock, k_bias_residual of pointwise.hip) with the GroupNorm
@@ -170,13 +188,11 @@ __global__ __launch_bounds__(256) void k_gn_stats_nhwc(const T* __restrict__ x, 
 // activation saved).  Same thread mapping as k_gn_stats_nhwc; the sums are taken over the values AS STORED (rounded to T).
 template <typename T>
 __global__ __launch_bounds__(256) void k_bias_residual_stats(const T* __restrict__ a, const T* __restrict__ bsrc, const T* __restrict__ bias, int hw,
-                                                             int C, int cg, int G, int slabs, int pix, T* __restrict__ out,
-                                                             double* __restrict__ stats) {
+                                                             int C, int cg, int G, int slabs, int pix, int hpg, T* __restrict__ out,
+                                                             float2* __restrict__ part) {
     constexpr int N = VecIO<T>::N;
-    __shared__ float sm[2 * 64];  // G <= 64
+    extern __shared__ __attribute__((aligned(16))) float2 gn_red[];  // [pixel lane][C]
     const int b = blockIdx.x / slabs, slab = blockIdx.x % slabs;
-    if (threadIdx.x < 2 * G) sm[threadIdx.x] = 0.f;
-    __syncthreads();
     const int vpp = C / N;
     const int p0 = slab * pix;
     const int p1 = (p0 + pix < hw) ? p0 + pix : hw;
@@ -208,28 +224,11 @@ __global__ __launch_bounds__(256) void k_bias_residual_stats(const T* __restrict
                 ss[j] = fmaf(t, t, ss[j]);
             }
         }
-        int gprev = (v * N) / cg;
-        float as = 0.f, ass = 0.f;
 #pragma unroll
-        for (int j = 0; j < N; ++j) {
-            const int g = (v * N + j) / cg;
-            if (g != gprev) {
-                atomicAdd(&sm[2 * gprev], as);
-                atomicAdd(&sm[2 * gprev + 1], ass);
-                as = ass = 0.f;
-                gprev = g;
-            }
-            as += s[j];
-            ass += ss[j];
-        }
-        atomicAdd(&sm[2 * gprev], as);
-        atomicAdd(&sm[2 * gprev + 1], ass);
+        for (int j = 0; j < N; ++j) gn_red[pl * C + v * N + j] = make_float2(s[j], ss[j]);
     }
     __syncthreads();
-    if (threadIdx.x < G) {
-        atomicAdd(&stats[(int64_t(b) * G + threadIdx.x) * 2], double(sm[2 * threadIdx.x]));
-        atomicAdd(&stats[(int64_t(b) * G + threadIdx.x) * 2 + 1], double(sm[2 * threadIdx.x + 1]));
-    }
+    gn_fold_store(gn_red, vpp < 256 ? 256 / vpp : 1, C, cg, G, hpg, part, b, slabs, slab);
 }
 
 // Apply pass, same thread mapping as the statistics pass: a thread owns one 16-byte channel vector column, so the
@@ -313,24 +312,41 @@ __global__ __launch_bounds__(256) void k_gn_apply_nhwc(const T* __restrict__ x, 
     }
 }
 
-template <typename T>
-static int gn_launch_nhwc(const void* x, const void* shift, int shift_bstride, int64_t B, int C, int hw, int G, const void* gamma, const void* beta, float eps, int silu,
-                          const void* residual, void* y, double* stats, hipStream_t s, bool have_stats = false) {
-    const int cg = C / G;
-    const int nstat = int(B) * G * 2;
-    if (!have_stats) hipLaunchKernelGGL(k_gn_zero, dim3((nstat + 255) / 256), dim3(256), 0, s, stats, nstat);
-    // pixels per workgroup: aim at ~1024 workgroups, at least one pixel per pixel lane, at most 256
-    const int vpp = C / VecIO<T>::N;
+// Launch plan of the channels-last statistics kernels: pixels per workgroup (aim at ~1024 workgroups, at least one pixel per
+// pixel lane, at most 256), slabs per image, helpers per group of the fold, LDS bytes.  The partial pairs live behind the B*G*2
+// moments in the caller's statistics buffer (xm3d_gn_stats_doubles_nhwc doubles in all).
+struct GnPlan {
+    int pix, slabs, hpg, lds;
+};
+static GnPlan gn_plan_nhwc(int64_t B, int C, int hw, int G, int nvec) {
+    GnPlan p;
+    const int vpp = C / nvec;
     const int lanes = vpp < 256 ? 256 / vpp : 1;
     int64_t pix = (B * int64_t(hw) + 1023) / 1024;
     if (pix < lanes) pix = lanes;
     if (pix > 256) pix = 256;
     if (pix > hw) pix = hw;
-    const int slabs = int((hw + pix - 1) / pix);
-    if (!have_stats)
-        hipLaunchKernelGGL(k_gn_stats_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift), shift_bstride, hw, C, cg, G, slabs, int(pix), stats);
-    hipLaunchKernelGGL(k_gn_apply_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift),
-                       shift_bstride, static_cast<const T*>(gamma), static_cast<const T*>(beta), stats, hw, C, cg, G, slabs, int(pix),
+    p.pix = int(pix);
+    p.slabs = int((hw + pix - 1) / pix);
+    p.hpg = 1;
+    while (p.hpg * 2 * G <= 256 && p.hpg < 64) p.hpg *= 2;
+    p.lds = lanes * C * int(sizeof(float2));
+    return p;
+}
+static float2* gn_partials(double* stats, int64_t B, int G) { return reinterpret_cast<float2*>(stats + B * G * 2); }
+
+template <typename T>
+static int gn_launch_nhwc(const void* x, const void* shift, int shift_bstride, int64_t B, int C, int hw, int G, const void* gamma, const void* beta, float eps, int silu,
+                          const void* residual, void* y, double* stats, hipStream_t s, bool have_stats = false) {
+    const int cg = C / G;
+    const GnPlan p = gn_plan_nhwc(B, C, hw, G, VecIO<T>::N);
+    if (!have_stats) {
+        float2* part = gn_partials(stats, B, G);
+        hipLaunchKernelGGL(k_gn_stats_nhwc<T>, dim3(unsigned(B * p.slabs)), dim3(256), p.lds, s, static_cast<const T*>(x), static_cast<const T*>(shift), shift_bstride, hw, C, cg, G, p.slabs, p.pix, p.hpg, part);
+        hipLaunchKernelGGL(k_gn_reduce, dim3(unsigned(B * G)), dim3(64), 0, s, part, p.slabs, stats);
+    }
+    hipLaunchKernelGGL(k_gn_apply_nhwc<T>, dim3(unsigned(B * p.slabs)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift),
+                       shift_bstride, static_cast<const T*>(gamma), static_cast<const T*>(beta), stats, hw, C, cg, G, p.slabs, p.pix,
                        1.0f / (float(cg) * float(hw)), eps, silu, static_cast<const T*>(residual), static_cast<T*>(y));
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
@@ -340,17 +356,11 @@ template <typename T>
 static int bias_residual_stats_launch(const void* a, const void* b, const void* bias, int64_t B, int C, int hw, int G, void* out, double* stats,
                                       hipStream_t s) {
     const int cg = C / G;
-    const int nstat = int(B) * G * 2;
-    hipLaunchKernelGGL(k_gn_zero, dim3((nstat + 255) / 256), dim3(256), 0, s, stats, nstat);
-    const int vpp = C / VecIO<T>::N;
-    const int lanes = vpp < 256 ? 256 / vpp : 1;
-    int64_t pix = (B * int64_t(hw) + 1023) / 1024;
-    if (pix < lanes) pix = lanes;
-    if (pix > 256) pix = 256;
-    if (pix > hw) pix = hw;
-    const int slabs = int((hw + pix - 1) / pix);
-    hipLaunchKernelGGL(k_bias_residual_stats<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(a), static_cast<const T*>(b),
-                       static_cast<const T*>(bias), hw, C, cg, G, slabs, int(pix), static_cast<T*>(out), stats);
+    const GnPlan p = gn_plan_nhwc(B, C, hw, G, VecIO<T>::N);
+    float2* part = gn_partials(stats, B, G);
+    hipLaunchKernelGGL(k_bias_residual_stats<T>, dim3(unsigned(B * p.slabs)), dim3(256), p.lds, s, static_cast<const T*>(a), static_cast<const T*>(b),
+                       static_cast<const T*>(bias), hw, C, cg, G, p.slabs, p.pix, p.hpg, static_cast<T*>(out), part);
+    hipLaunchKernelGGL(k_gn_reduce, dim3(unsigned(B * G)), dim3(64), 0, s, part, p.slabs, stats);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
@@ -361,9 +371,9 @@ static int gn_launch(const void* x, int64_t B, int C, int hw, int G, const void*
     const int cg = C / G;
     const int64_t group_elems = int64_t(cg) * hw;
     const int slices = int((group_elems + GN_SLICE - 1) / GN_SLICE);
-    const int nstat = int(B) * G * 2;
-    hipLaunchKernelGGL(k_gn_zero, dim3((nstat + 255) / 256), dim3(256), 0, s, stats, nstat);
-    hipLaunchKernelGGL(k_gn_stats<T>, dim3(unsigned(B * G * slices)), dim3(256), 0, s, static_cast<const T*>(x), group_elems, slices, stats);
+    float2* part = gn_partials(stats, B, G);
+    hipLaunchKernelGGL(k_gn_stats<T>, dim3(unsigned(B * G * slices)), dim3(256), 0, s, static_cast<const T*>(x), group_elems, slices, part);
+    hipLaunchKernelGGL(k_gn_reduce, dim3(unsigned(B * G)), dim3(64), 0, s, part, slices, stats);
     const int64_t nvec = B * C * int64_t(hw) / VecIO<T>::N;
     int64_t blocks = (nvec + 255) / 256;
     if (blocks > 4096) blocks = 4096;
@@ -394,23 +404,27 @@ extern "C" int xm3d_group_norm(const void* x, int32_t dtype, int64_t B, int32_t 
 template <typename T>
 static int gn_stats_only_nhwc(const void* x, const void* shift, int shift_bstride, int64_t B, int C, int hw, int G, double* stats, hipStream_t s) {
     const int cg = C / G;
-    const int nstat = int(B) * G * 2;
-    hipLaunchKernelGGL(k_gn_zero, dim3((nstat + 255) / 256), dim3(256), 0, s, stats, nstat);
-    const int vpp = C / VecIO<T>::N;
-    const int lanes = vpp < 256 ? 256 / vpp : 1;
-    int64_t pix = (B * int64_t(hw) + 1023) / 1024;
-    if (pix < lanes) pix = lanes;
-    if (pix > 256) pix = 256;
-    if (pix > hw) pix = hw;
-    const int slabs = int((hw + pix - 1) / pix);
-    hipLaunchKernelGGL(k_gn_stats_nhwc<T>, dim3(unsigned(B * slabs)), dim3(256), 0, s, static_cast<const T*>(x), static_cast<const T*>(shift), shift_bstride, hw, C, cg, G, slabs, int(pix), stats);
+    const GnPlan p = gn_plan_nhwc(B, C, hw, G, VecIO<T>::N);
+    float2* part = gn_partials(stats, B, G);
+    hipLaunchKernelGGL(k_gn_stats_nhwc<T>, dim3(unsigned(B * p.slabs)), dim3(256), p.lds, s, static_cast<const T*>(x), static_cast<const T*>(shift), shift_bstride, hw, C, cg, G, p.slabs, p.pix, p.hpg, part);
+    hipLaunchKernelGGL(k_gn_reduce, dim3(unsigned(B * G)), dim3(64), 0, s, part, p.slabs, stats);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
 
+extern "C" int64_t xm3d_gn_stats_doubles_nhwc(int64_t B, int32_t C, int32_t hw, int32_t G, int32_t dtype) {
+    if (B <= 0 || C <= 0 || hw <= 0 || G <= 0 || C % G != 0 || C % (dtype == 0 ? 4 : 8) != 0) return B > 0 && G > 0 ? B * G * 2 : 0;
+    return B * G * 2 + B * G * int64_t(gn_plan_nhwc(B, C, hw, G, dtype == 0 ? 4 : 8).slabs);
+}
+
+extern "C" int64_t xm3d_gn_stats_doubles_nchw(int64_t B, int32_t C, int32_t hw, int32_t G) {
+    if (B <= 0 || C <= 0 || hw <= 0 || G <= 0 || C % G != 0) return 0;
+    return B * G * 2 + B * G * ((int64_t(C / G) * hw + GN_SLICE - 1) / GN_SLICE);
+}
+
 extern "C" int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,
                                           int32_t G, double* stats, void* stream) {
-    XM3D_REQUIRE(B >= 0 && C >= 1 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "group_norm_nhwc_stats: bad shape B=%lld C=%d hw=%d G=%d",
+    XM3D_REQUIRE(B >= 0 && C >= 1 && C <= 8192 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "group_norm_nhwc_stats: bad shape B=%lld C=%d hw=%d G=%d",
                  (long long)B, C, hw, G);
     XM3D_REQUIRE(dtype == 0 || dtype == 1, "group_norm_nhwc_stats: dtype must be 0 (f32) or 1 (bf16)");
     if (B == 0) return XM3D_OK;
@@ -426,7 +440,7 @@ extern "C" int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int3
 extern "C" int xm3d_group_norm_nhwc_res(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C,
                                         int32_t hw, int32_t G, const void* gamma, const void* beta, float eps, int32_t silu,
                                         const void* residual, void* y, double* stats_ws, void* stream) {
-    XM3D_REQUIRE(B >= 0 && C >= 1 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "group_norm_nhwc: bad shape B=%lld C=%d hw=%d G=%d",
+    XM3D_REQUIRE(B >= 0 && C >= 1 && C <= 8192 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "group_norm_nhwc: bad shape B=%lld C=%d hw=%d G=%d",
                  (long long)B, C, hw, G);
     XM3D_REQUIRE(dtype == 0 || dtype == 1, "group_norm_nhwc: dtype must be 0 (f32) or 1 (bf16)");
     if (B == 0) return XM3D_OK;
@@ -450,7 +464,7 @@ extern "C" int xm3d_group_norm_nhwc(const void* x, const void* shift, int32_t sh
 
 extern "C" int xm3d_bias_residual_stats_nhwc(const void* a, const void* b, const void* bias, int32_t dtype, int64_t B, int32_t C, int32_t hw,
                                              int32_t G, void* out, double* stats, void* stream) {
-    XM3D_REQUIRE(B >= 0 && C >= 1 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "bias_residual_stats: bad shape B=%lld C=%d hw=%d G=%d",
+    XM3D_REQUIRE(B >= 0 && C >= 1 && C <= 8192 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "bias_residual_stats: bad shape B=%lld C=%d hw=%d G=%d",
                  (long long)B, C, hw, G);
     XM3D_REQUIRE(dtype == 0 || dtype == 1, "bias_residual_stats: dtype must be 0 (f32) or 1 (bf16)");
     if (B == 0) return XM3D_OK;
@@ -467,7 +481,7 @@ extern "C" int xm3d_bias_residual_stats_nhwc(const void* a, const void* b, const
 extern "C" int xm3d_group_norm_nhwc_apply(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C,
                                           int32_t hw, int32_t G, const void* gamma, const void* beta, float eps, int32_t silu,
                                           const void* residual, void* y, const double* stats, void* stream) {
-    XM3D_REQUIRE(B >= 0 && C >= 1 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "group_norm_nhwc_apply: bad shape B=%lld C=%d hw=%d G=%d",
+    XM3D_REQUIRE(B >= 0 && C >= 1 && C <= 8192 && hw >= 1 && G >= 1 && G <= 64 && C % G == 0, "group_norm_nhwc_apply: bad shape B=%lld C=%d hw=%d G=%d",
                  (long long)B, C, hw, G);
     XM3D_REQUIRE(dtype == 0 || dtype == 1, "group_norm_nhwc_apply: dtype must be 0 (f32) or 1 (bf16)");
     if (B == 0) return XM3D_OK;

@@ -258,11 +258,10 @@ extern "C" int xm3d_mask_logits_bias(const void* mask_embed, const void* mask_fe
     a.bias = bias;
     a.B = int(B), a.Q = Q, a.H = H, a.W = W, a.h = h, a.w = w;
     a.bias_is_bf16 = bias_dtype;
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce configured;  // the attribute is per device
+    if (configured.first()) {
         XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mask_logits_bias<true>), hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS));
         XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_mask_logits_bias<false>), hipFuncAttributeMaxDynamicSharedMemorySize, MH_LDS));
-        configured = true;
     }
     // workgroups per image: enough to fill the chip twice over, at most one per band; each stages the embedding once
     const int per_image = int(std::min<int64_t>(h, std::max<int64_t>(1, (512 + B - 1) / B)));

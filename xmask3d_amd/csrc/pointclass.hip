@@ -140,10 +140,9 @@ extern "C" int xm3d_point_class(const float* x, int64_t ldx, const int64_t* row_
     a.masks = masks, a.vid = vid, a.open_p = open_p, a.overlap = overlap, a.label = label;
     a.np = np, a.ldx = ldx, a.C = C, a.K = K, a.Q = Q, a.mode = mode, a.base_ratio = base_ratio, a.novel_ratio = novel_ratio;
     const int lds = (K / 8) * 64 * 16 + 4 * 32 * PC_TSTR * 4;
-    static bool configured = false;
-    if (!configured) {
+    static DeviceOnce configured;  // the attribute is per device
+    if (configured.first()) {
         XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_point_class), hipFuncAttributeMaxDynamicSharedMemorySize, 1024 / 8 * 64 * 16 + 4 * 32 * PC_TSTR * 4));
-        configured = true;
     }
     const int64_t ntile = (np + 31) / 32;
     const unsigned grid = unsigned(std::min<int64_t>((ntile + 3) / 4, 512));

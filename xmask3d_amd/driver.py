@@ -73,11 +73,23 @@ def synthetic_labels(scene, n_classes=19, seed=0):
     return torch.from_numpy(((band * 4 + quad + seed) % n_classes).astype(np.int64))
 
 
+def _log_pretrained(model, log):
+    """say which frozen-net files the model was built from (checkpoint.load_pretrained raises on a refused file / partial set)"""
+    rep = getattr(model, "pretrained_report", None)
+    if rep is None:
+        log("pretrained: no SD / CLIP / tokenizer files found - seeded random frozen nets, stand-in tokenizer (synthetic runs only)")
+        return
+    log(f"pretrained: SD {rep['sd']}, CLIP {rep['clip']}, tokenizer {rep['tokenizer']}, uncond_inputs {rep['uncond']}")
+    for pr in rep.get("problems", []):
+        log("pretrained: WARNING " + pr)
+
+
 def train(cfg, epochs=1, iters_per_epoch=4, views_per_gpu=2, save_path=None, resume=None, log=print):
     rank, world, dev = setup_distributed(cfg)
     torch.manual_seed(cfg.manual_seed)
     np.random.seed(cfg.manual_seed + rank)
     model = XMASK3d(cfg).to(dev)
+    _log_pretrained(model, log)
     if dev.type == "cuda" and bool(getattr(cfg, "train_unet_graph", True)):
         # the frozen UNet's forward + backward replay as HIP graphs (it has no trainable parameter: DDP never sees it)
         model.backbone.feature_extractor.ldm_extractor.enable_train_graph()
@@ -154,6 +166,7 @@ def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, lo
     if own:
         torch.manual_seed(cfg.manual_seed)
         model = XMASK3d(cfg).to(dev)
+        _log_pretrained(model, log)
         if resume:
             ckpt_io.load_checkpoint(resume, model, eval=True, map_location=dev)
     model = model.module if hasattr(model, "module") else model

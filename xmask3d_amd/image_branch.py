@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .sd_model import ACT_NONE, ACT_RELU, AutoencoderKL, UNetModel, _gn_f32, _packed, _packed_split, fused_conv_ok, gn_act
+from .sd_model import ACT_NONE, ACT_RELU, AutoencoderKL, UNetModel, _gn_f32, _packed, _packed_split, fused_conv_ok, gn_act, own_conv
 
 SCALE_FACTOR = 0.18215
 # sqrt(alphas_cumprod[0]) and sqrt(1 - alphas_cumprod[0]) of the "ldm_linear" schedule
@@ -307,7 +307,13 @@ class _ConvGN(nn.Conv2d):
     def forward(self, x, residual=None, relu=None):
         """residual / relu: the tail of the bottleneck, relu(norm(conv(x)) + residual), in the GroupNorm's apply pass"""
         relu = self._relu if relu is None else relu
-        return gn_act(self.norm, super().forward(x), ACT_RELU if relu else ACT_NONE, residual=residual)
+        return gn_act(self.norm, self.conv_only(x), ACT_RELU if relu else ACT_NONE, residual=residual)
+
+    def conv_only(self, x):
+        """the convolution without its norm: the implicit-GEMM kernel on channels-last bf16 inference (bit-reproducible; the
+        library's 1x1 convolutions at K >= 512 were not), torch otherwise"""
+        out = own_conv(self, x)
+        return out if out is not None else nn.Conv2d.forward(self, x)
 
 
 class GNBottleneck(nn.Module):
@@ -321,7 +327,7 @@ class GNBottleneck(nn.Module):
     def forward(self, x):
         # detectron2 BottleneckBlock: relu(conv3(...) + shortcut); add + ReLU ride in conv3's GroupNorm apply pass
         res = self.shortcut(x) if self.shortcut is not None else x
-        c1 = nn.Conv2d.forward(self.conv1, x)
+        c1 = self.conv1.conv_only(x)
         if fused_conv_ok(c1, self.conv2):
             # the 3x3 convolution on the HIP kernel: conv1's GroupNorm + ReLU are applied while its input tile is staged (one
             # statistics pass over conv1's output instead of statistics + apply), and the moments for conv2's own GroupNorm come

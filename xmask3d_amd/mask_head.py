@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .sd_model import ACT_NONE, ACT_RELU, gn_act
+from .sd_model import ACT_NONE, ACT_RELU, Conv2d, fused_conv_ok, gn_act, own_conv, plain_conv3x3
 from .msda import MSDeformAttn
 
 
@@ -149,9 +149,13 @@ class _Conv(nn.Conv2d):
             self.norm = nn.GroupNorm(32, cout)
         self._gn, self._relu = gn, relu
 
+    def _conv(self, x):
+        out = _head_conv(self, x)
+        return out if out is not None else nn.Conv2d.forward(self, x)
+
     def forward(self, x, residual=None):
         """residual: added after the norm, before the ReLU (the FPN's top-down term rides in the GroupNorm apply pass)"""
-        x = super().forward(x)
+        x = self._conv(x)
         if self._gn:
             if _fused_inference(x):
                 # bf16 inference under autocast: the fused channels-last GroupNorm(+residual)(+ReLU) kernel, bf16 out - the
@@ -161,6 +165,17 @@ class _Conv(nn.Conv2d):
         if residual is not None:
             x = x + residual
         return F.relu_(x) if self._relu else x
+
+
+def _head_conv(conv, x):
+    """a convolution of the pixel decoder on the own kernels where they apply (channels-last bf16 inference with bf16 weight copies:
+    cast_head_weights): the 3x3 output convolutions on the halo-tile kernel - the moments of the result for the GroupNorm behind it
+    come out of the epilogue - the 1x1 lateral / projection convolutions on the implicit-GEMM kernel.  None: use torch."""
+    if not (_fused_inference(x) and conv.weight.dtype == torch.bfloat16):
+        return None
+    if conv.kernel_size == (3, 3) and fused_conv_ok(x, conv):
+        return plain_conv3x3(conv, x)
+    return own_conv(conv, x)
 
 
 def _fused_inference(x):
@@ -187,7 +202,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         self.transformer_feature_strides = [v[1] for _, v in titems]
         self.transformer_num_feature_levels = len(titems)
         self.input_proj = nn.ModuleList(
-            nn.Sequential(nn.Conv2d(v[0], conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for _, v in titems[::-1])
+            nn.Sequential(Conv2d(v[0], conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for _, v in titems[::-1])
         for proj in self.input_proj:
             nn.init.xavier_uniform_(proj[0].weight, gain=1)
             nn.init.constant_(proj[0].bias, 0)

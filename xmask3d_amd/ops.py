@@ -389,6 +389,12 @@ def _act_torch(y, act):
     return y * torch.sigmoid(y) if act == 1 else (torch.relu_(y) if act == 2 else y)
 
 
+def _gn_stats_buf(x, B, C, hw, G):
+    """statistics buffer of the channels-last GroupNorm kernels: B*G*2 f64 moments followed by the per-workgroup partial pairs they are
+    summed from in fixed order (xm3d.h, "STATISTICS BUFFERS")"""
+    return torch.empty(lib().xm3d_gn_stats_doubles_nhwc(B, C, hw, G, 0 if x.dtype == torch.float32 else 1), dtype=torch.float64, device=x.device)
+
+
 def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False, shift=None, residual=None):
     """NCHW, channels-last or (B,C,L) f32/bf16 device tensor -> same shape/dtype/layout; statistics in f64, math in f32.
     silu: False/0 none, True/1 SiLU, 2 ReLU fused after the affine.
@@ -403,9 +409,9 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False, shif
     for t in (weight, bias):
         if t is not None and (t.dtype != x.dtype or not t.is_contiguous() or t.numel() != C):
             raise TypeError("group_norm: weight/bias must be contiguous (C,) tensors of the input dtype")
-    stats = torch.empty(B * num_groups * 2, dtype=torch.float64, device=x.device)
     nvec = 4 if x.dtype == torch.float32 else 8
     if is_nhwc(x) and C % nvec == 0 and num_groups <= 64:
+        stats = _gn_stats_buf(x, B, C, hw, num_groups)
         y = torch.empty_like(x)  # preserves channels_last
         bstride = 0
         if shift is not None:
@@ -436,6 +442,7 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False, shif
     if not x.is_contiguous():
         x = x.contiguous()
     y = torch.empty_like(x)
+    stats = torch.empty(lib().xm3d_gn_stats_doubles_nchw(B, C, hw, num_groups), dtype=torch.float64, device=x.device)
     check(lib().xm3d_group_norm(_ptr(x), 0 if x.dtype == torch.float32 else 1, B, C, hw, num_groups, _ptr(weight), _ptr(bias),
                                 float(eps), 0 if residual is not None else int(silu), _ptr(y), _ptr(stats), _stream()), "xm3d_group_norm")
     return y if residual is None else _act_torch(y + residual, silu)
@@ -453,10 +460,10 @@ def bias_residual(a, b, bias, stats_groups=None):
     if stats_groups and C % stats_groups == 0 and stats_groups <= 64:
         # also accumulate the GroupNorm statistics of the result: the GroupNorm that reads it next skips its statistics pass
         # (group_norm() picks them up from the tensor; they describe exactly this storage, so never modify it in place)
-        stats = torch.empty(Bn * stats_groups * 2, dtype=torch.float64, device=b.device)
+        stats = _gn_stats_buf(b, Bn, C, H * W, int(stats_groups))
         check(lib().xm3d_bias_residual_stats_nhwc(_ptr(a), _ptr(b), _ptr(bias.contiguous()), 0 if b.dtype == torch.float32 else 1, Bn, C, H * W,
                                                   int(stats_groups), _ptr(out), _ptr(stats), _stream()), "xm3d_bias_residual_stats_nhwc")
-        out._xm3d_gn_stats = (stats, int(stats_groups), out.data_ptr())
+        out._xm3d_gn_stats = (stats[:Bn * stats_groups * 2], int(stats_groups), out.data_ptr())
         return out
     check(lib().xm3d_bias_residual_nhwc(_ptr(a), _ptr(b), _ptr(bias.contiguous()), 0 if b.dtype == torch.float32 else 1, Bn * H * W, C,
                                         _ptr(out), _stream()), "xm3d_bias_residual_nhwc")
@@ -474,7 +481,7 @@ def gn_stats_of(x, num_groups=32, shift=None):
     if not is_nhwc(x) or x.dtype not in (torch.float32, torch.bfloat16):
         raise TypeError("gn_stats_of: channels-last f32/bf16 device tensor required")
     B, C, H, W = x.shape
-    stats = torch.empty(B * num_groups * 2, dtype=torch.float64, device=x.device)
+    stats = _gn_stats_buf(x, B, C, H * W, num_groups)
     bstride = 0
     if shift is not None:
         shift = shift.to(x.dtype).contiguous()
@@ -483,7 +490,7 @@ def gn_stats_of(x, num_groups=32, shift=None):
         bstride = C if (shift.numel() == B * C and B > 1) else 0
     check(lib().xm3d_group_norm_nhwc_stats(_ptr(x), _ptr(shift), bstride, 0 if x.dtype == torch.float32 else 1, B, C, H * W, num_groups, _ptr(stats),
                                            _stream()), "xm3d_group_norm_nhwc_stats")
-    return stats
+    return stats[:B * num_groups * 2]
 
 
 def conv3x3_supported(x, cout, upsample=False):
@@ -563,9 +570,10 @@ def conv3x3_f32(x, packs, cout, tile, bias=None, gn=None, residual=None, stats_g
         bstride = cout if (bias.numel() == B * cout and B > 1) else 0
     if residual is not None and not (is_nhwc(residual) and residual.dtype == torch.float32 and residual.shape == out.shape):
         raise TypeError("conv3x3_f32: residual must be a channels-last f32 tensor of the output's shape")
-    stats_out = torch.zeros(B * stats_groups * 2, dtype=torch.float64, device=x.device) if stats_groups else None
-    L = lib().xm3d_conv3x3_nhwc_f32acc
     u, wv = int(bool(upsample)), int(waves) or _CONV_WAVES
+    stats_out = torch.empty(lib().xm3d_conv3x3_stats_doubles(B, H, W, cout, tile, int(stats_groups), wv), dtype=torch.float64,
+                            device=x.device) if stats_groups else None
+    L = lib().xm3d_conv3x3_nhwc_f32acc
     pairs = [(0, 0), (0, 1), (1, 0)] + ([(0, 2), (2, 0), (1, 1)] if terms == 3 else [])
     for n, (i, j) in enumerate(pairs):
         first, last = n == 0, n == len(pairs) - 1
@@ -573,7 +581,7 @@ def conv3x3_f32(x, packs, cout, tile, bias=None, gn=None, residual=None, stats_g
                 _ptr(residual) if first else _ptr(out), _ptr(out), _ptr(stats_out) if last else None, int(stats_groups or 0) if last else 0, u, wv,
                 _stream()), "xm3d_conv3x3_nhwc_f32acc")
     if stats_out is not None:
-        out._xm3d_gn_stats = (stats_out, int(stats_groups), out.data_ptr())
+        out._xm3d_gn_stats = (stats_out[:B * stats_groups * 2], int(stats_groups), out.data_ptr())
     return out
 
 
@@ -645,6 +653,47 @@ def gemm(x, packed, n_rows, tile, bias=None, act=None, residual=None, waves=0):
     return out
 
 
+def conv_gemm_supported(x, weight_shape):
+    """channels-last bf16 image and a Conv2d weight (cout, cin, k, k), k <= 3, cin % 64 == 0 (xm3d_conv_gemm_bf16)"""
+    return (is_nhwc(x) and x.dtype == torch.bfloat16 and len(weight_shape) == 4 and weight_shape[2] == weight_shape[3] and weight_shape[2] in (1, 2, 3)
+            and weight_shape[1] == x.shape[1] and weight_shape[1] % 64 == 0)
+
+
+def conv_gemm_pack_weight(weight):
+    """Conv2d weight (cout, cin, k, k) -> (packed bf16 image, column tile, padded cout): rows in (ky, kx, cin) order, cout padded with
+    zero rows to a multiple of 32"""
+    cout, cin, k, _ = weight.shape
+    w = weight.detach().float().permute(0, 2, 3, 1).reshape(cout, k * k * cin)
+    n32 = (cout + 31) // 32 * 32
+    if n32 != cout:
+        w = torch.cat([w, torch.zeros(n32 - cout, w.shape[1], dtype=w.dtype, device=w.device)])
+    packed, tile = gemm_pack_weight(w.contiguous())
+    return packed, tile, n32
+
+
+def conv_gemm(x, packed, tile, n32, cout, ksize, stride=1, padding=(0, 0, 0, 0), bias=None, residual=None):
+    """conv2d(x, W, stride, zero padding (top, left, bottom, right)) + bias (+ residual) as an implicit GEMM (csrc/gemm.hip GF_CONV):
+    x (B, cin, H, W) channels-last bf16 -> (B, cout, Ho, Wo) channels-last bf16.  bias f32 (n32,) or None; residual like the output
+    (cout == n32 only).  Bit-reproducible (deterministic split-K on small grids)."""
+    if not (is_nhwc(x) and x.dtype == torch.bfloat16):
+        raise TypeError(f"conv_gemm: channels-last bf16 device tensor required, got {tuple(x.shape)} {x.dtype}")
+    B, cin, H, W = x.shape
+    pt, pl, pb, pr = (int(p) for p in padding)
+    Ho, Wo = (H + pt + pb - ksize) // stride + 1, (W + pl + pr - ksize) // stride + 1
+    out = torch.empty((B, Ho, Wo, n32), dtype=torch.bfloat16, device=x.device)
+    if residual is not None:
+        if n32 != cout or residual.dtype != torch.bfloat16 or tuple(residual.shape) != (B, cout, Ho, Wo) or not is_nhwc(residual):
+            raise TypeError("conv_gemm: residual must be a channels-last bf16 tensor of the output's shape")
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != n32):
+        raise TypeError("conv_gemm: bias must be a contiguous f32 (padded cout,) tensor")
+    nb = lib().xm3d_conv_gemm_ws_bytes(B * Ho * Wo, n32, ksize * ksize * cin, tile)
+    ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device) if nb else None
+    check(lib().xm3d_conv_gemm_bf16(_ptr(x), B, H, W, cin, _ptr(packed), n32, tile, ksize, stride, pt, pl, Ho, Wo, _ptr(bias), _ptr(residual), _ptr(out),
+                                    _ptr(ws), _stream()), "xm3d_conv_gemm_bf16")
+    img = out.permute(0, 3, 1, 2)
+    return img if n32 == cout else img[:, :cout].contiguous(memory_format=torch.channels_last)
+
+
 _CONV_WAVES = int(_os.environ.get("XM3D_CONV_WAVES", "0"))  # A/B switch for bench runs: force one workgroup geometry (0 = per-layer choice)
 
 
@@ -684,14 +733,15 @@ def conv3x3(x, packed, cout, tile, bias=None, gn=None, residual=None, stats_grou
         sstride = cin if (in_shift.numel() == B * cin and B > 1) else 0
     stats_out = ws = None
     if stats_groups:
-        stats_out = torch.zeros(B * stats_groups * 2, dtype=torch.float64, device=x.device)
+        stats_out = torch.empty(lib().xm3d_conv3x3_stats_doubles(B, H, W, cout, tile, int(stats_groups), int(waves) or _CONV_WAVES),
+                                dtype=torch.float64, device=x.device)
     if gn is not None:
         ws = torch.empty(B * cin * 2, dtype=torch.float32, device=x.device)
     check(lib().xm3d_conv3x3_nhwc(_ptr(x), B, H, W, cin, _ptr(packed), cout, tile, _ptr(stats_in), _ptr(gamma), _ptr(beta), _ptr(in_shift), sstride,
                                   float(eps), int(G), act, _ptr(bias), bstride, _ptr(residual), _ptr(out), _ptr(stats_out), int(stats_groups or 0), int(bool(upsample)),
                                   int(waves) or _CONV_WAVES, _ptr(ws), _stream()), "xm3d_conv3x3_nhwc")
     if stats_out is not None:
-        out._xm3d_gn_stats = (stats_out, int(stats_groups), out.data_ptr())
+        out._xm3d_gn_stats = (stats_out[:B * stats_groups * 2], int(stats_groups), out.data_ptr())
     return out
 
 

@@ -47,7 +47,54 @@ def fused_nhwc(x):
             and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last) and x.shape[1] % 8 == 0)
 
 
+_CONV_GEMM_LIBRARY = os.environ.get("XM3D_CONV_GEMM", "hip") == "library"  # A/B switch: strided / small-map / 1x1 convolutions back on MIOpen
+
+
+def _packed_cg(conv):
+    """(packed image, column tile, padded cout, padded f32 bias or None) of a frozen Conv2d for ops.conv_gemm, once per weight storage"""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.dtype)
+    c = conv.__dict__.get("_xm3d_cg")
+    if c is None or c[0] != key:
+        packed, tile, n32 = ops.conv_gemm_pack_weight(w)
+        bias = None
+        if conv.bias is not None:
+            bias = torch.zeros(n32, dtype=torch.float32, device=w.device)
+            bias[:conv.out_channels] = conv.bias.detach().float()
+        c = conv.__dict__["_xm3d_cg"] = (key, packed, tile, n32, bias)
+    return c[1:]
+
+
+def own_conv(conv, x, with_bias=True, residual=None, padding=None):
+    """Conv2d on the implicit-GEMM kernel (csrc/gemm.hip GF_CONV, ops.conv_gemm) - the convolutions the halo-tile kernel does not
+    take: strided Downsample, the 16^2 / 8^2 UNet levels, 1x1 - or None when the call is not channels-last bf16 inference on a shape
+    the kernel takes (the caller then uses torch).  padding: (top, left, bottom, right) overriding the module's symmetric padding
+    (the VAE Downsample pads bottom / right only).  Unlike the library's split-K convolutions these are bit-reproducible."""
+    if _CONV_GEMM_LIBRARY or torch.is_grad_enabled() or not fused_nhwc(x) or x.dtype != torch.bfloat16 or conv.weight.dtype != torch.bfloat16:
+        return None
+    k = conv.kernel_size
+    if not (k[0] == k[1] and k[0] <= 3 and conv.stride[0] == conv.stride[1] and conv.dilation == (1, 1) and conv.groups == 1
+            and isinstance(conv.padding, tuple) and conv.in_channels % 64 == 0 and x.shape[1] == conv.in_channels):
+        return None
+    packed, tile, n32, bias = _packed_cg(conv)
+    if residual is not None and n32 != conv.out_channels:
+        return None
+    pad = padding if padding is not None else (conv.padding[0], conv.padding[1], conv.padding[0], conv.padding[1])
+    return ops.conv_gemm(x, packed, tile, n32, conv.out_channels, k[0], conv.stride[0], pad, bias=bias if with_bias else None, residual=residual)
+
+
+class Conv2d(nn.Conv2d):
+    """nn.Conv2d of the frozen nets: channels-last bf16 inference runs the own kernels (own_conv), everything else torch"""
+
+    def forward(self, x):
+        out = own_conv(self, x)
+        return out if out is not None else super().forward(x)
+
+
 def conv_nobias(conv: nn.Conv2d, x):
+    out = own_conv(conv, x, with_bias=False)
+    if out is not None:
+        return out
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
@@ -236,11 +283,11 @@ class VaeResBlock(nn.Module):
         super().__init__()
         self.in_channels, self.out_channels = cin, cout
         self.norm1 = group_norm(cin, 1e-6)
-        self.conv1 = nn.Conv2d(cin, cout, 3, padding=1)
+        self.conv1 = Conv2d(cin, cout, 3, padding=1)
         self.norm2 = group_norm(cout, 1e-6)
-        self.conv2 = nn.Conv2d(cout, cout, 3, padding=1)
+        self.conv2 = Conv2d(cout, cout, 3, padding=1)
         if cin != cout:
-            self.nin_shortcut = nn.Conv2d(cin, cout, 1)
+            self.nin_shortcut = Conv2d(cin, cout, 1)
 
     def forward(self, x, temb=None, pend=None):
         """pend: (C,) bias of the convolution that produced x and has NOT been added yet (conv_in / Downsample / Upsample of
@@ -285,10 +332,10 @@ class VaeAttnBlock(nn.Module):
     def __init__(self, c):
         super().__init__()
         self.norm = group_norm(c, 1e-6)
-        self.q = nn.Conv2d(c, c, 1)
-        self.k = nn.Conv2d(c, c, 1)
-        self.v = nn.Conv2d(c, c, 1)
-        self.proj_out = nn.Conv2d(c, c, 1)
+        self.q = Conv2d(c, c, 1)
+        self.k = Conv2d(c, c, 1)
+        self.v = Conv2d(c, c, 1)
+        self.proj_out = Conv2d(c, c, 1)
 
     def forward(self, x):
         h = gn_act(self.norm, x)
@@ -322,11 +369,14 @@ class VaeAttnBlock(nn.Module):
 class VaeDownsample(nn.Module):
     def __init__(self, c):
         super().__init__()
-        self.conv = nn.Conv2d(c, c, 3, stride=2, padding=0)
+        self.conv = Conv2d(c, c, 3, stride=2, padding=0)
 
     def forward(self, x, defer_bias=False):
         """defer_bias: return (conv output WITHOUT its bias, bias) when the fused channels-last path applies, else (out, None)"""
         if fused_nhwc(x) and not torch.is_grad_enabled():
+            out = own_conv(self.conv, x, with_bias=not defer_bias, padding=(0, 0, 1, 1))  # the (0,1,0,1) padding is the kernel's border handling
+            if out is not None:
+                return (out, self.conv.bias) if defer_bias else out
             xp = ops.pad_bottom_right_nhwc(x, 1, 1)  # one pass instead of F.pad's fill + strided copy
             if defer_bias:
                 return conv_nobias(self.conv, xp), self.conv.bias
@@ -338,7 +388,7 @@ class VaeDownsample(nn.Module):
 class VaeUpsample(nn.Module):
     def __init__(self, c):
         super().__init__()
-        self.conv = nn.Conv2d(c, c, 3, padding=1)
+        self.conv = Conv2d(c, c, 3, padding=1)
 
     def forward(self, x, defer_bias=False):
         if fused_conv_ok(x, self.conv, upsample=True):  # the nearest 2x upsampling is a shift of the staging address
@@ -373,7 +423,7 @@ class VaeEncoder(nn.Module):
     def __init__(self, ch=128, ch_mult=(1, 2, 4, 4), num_res_blocks=2, in_channels=3, z_channels=4):
         super().__init__()
         self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
-        self.conv_in = nn.Conv2d(in_channels, ch, 3, padding=1)
+        self.conv_in = Conv2d(in_channels, ch, 3, padding=1)
         self.down = nn.ModuleList()
         cin = ch
         for i, m in enumerate(ch_mult):
@@ -386,7 +436,7 @@ class VaeEncoder(nn.Module):
             self.down.append(lvl)
         self.mid = _Mid(cin)
         self.norm_out = group_norm(cin, 1e-6)
-        self.conv_out = nn.Conv2d(cin, 2 * z_channels, 3, padding=1)
+        self.conv_out = Conv2d(cin, 2 * z_channels, 3, padding=1)
 
     def forward(self, x, taps=()):
         """taps: flat block indices (level*num_res_blocks + block) whose input is recorded."""
@@ -415,7 +465,7 @@ class VaeDecoder(nn.Module):
         super().__init__()
         self.num_resolutions, self.num_res_blocks = len(ch_mult), num_res_blocks
         cin = ch * ch_mult[-1]
-        self.conv_in = nn.Conv2d(z_channels, cin, 3, padding=1)
+        self.conv_in = Conv2d(z_channels, cin, 3, padding=1)
         self.mid = _Mid(cin)
         self.up = nn.ModuleList([_Level() for _ in ch_mult])
         for i in reversed(range(len(ch_mult))):
@@ -425,7 +475,7 @@ class VaeDecoder(nn.Module):
             if i != 0:
                 self.up[i].upsample = VaeUpsample(cin)
         self.norm_out = group_norm(cin, 1e-6)
-        self.conv_out = nn.Conv2d(cin, out_ch, 3, padding=1)
+        self.conv_out = Conv2d(cin, out_ch, 3, padding=1)
 
     def forward(self, z, taps=(), stop_after_taps=False):
         """taps: flat indices over (level descending, block ascending).  With stop_after_taps the decoder
@@ -455,8 +505,8 @@ class AutoencoderKL(nn.Module):
         super().__init__()
         self.encoder = VaeEncoder()
         self.decoder = VaeDecoder()
-        self.quant_conv = nn.Conv2d(8, 8, 1)
-        self.post_quant_conv = nn.Conv2d(4, 4, 1)
+        self.quant_conv = Conv2d(8, 8, 1)
+        self.post_quant_conv = Conv2d(4, 4, 1)
 
 
 # ----------------------------------------------------------------------------- UNet
@@ -471,10 +521,10 @@ class UNetResBlock(nn.Module):
     def __init__(self, cin, emb_ch, cout):
         super().__init__()
         self.channels, self.out_channels = cin, cout
-        self.in_layers = nn.Sequential(group_norm(cin, 1e-5), nn.SiLU(), nn.Conv2d(cin, cout, 3, padding=1))
+        self.in_layers = nn.Sequential(group_norm(cin, 1e-5), nn.SiLU(), Conv2d(cin, cout, 3, padding=1))
         self.emb_layers = nn.Sequential(nn.SiLU(), nn.Linear(emb_ch, cout))
-        self.out_layers = nn.Sequential(group_norm(cout, 1e-5), nn.SiLU(), nn.Dropout(0.0), nn.Conv2d(cout, cout, 3, padding=1))
-        self.skip_connection = nn.Identity() if cin == cout else nn.Conv2d(cin, cout, 1)
+        self.out_layers = nn.Sequential(group_norm(cout, 1e-5), nn.SiLU(), nn.Dropout(0.0), Conv2d(cout, cout, 3, padding=1))
+        self.skip_connection = nn.Identity() if cin == cout else Conv2d(cin, cout, 1)
 
     def forward(self, x, emb):
         if fused_conv_ok(x, self.in_layers[2]) and self.out_channels % 64 == 0:
@@ -597,9 +647,9 @@ class SpatialTransformer(nn.Module):
     def __init__(self, c, heads, dim_head, context_dim=768):
         super().__init__()
         self.norm = group_norm(c, 1e-6)
-        self.proj_in = nn.Conv2d(c, heads * dim_head, 1)
+        self.proj_in = Conv2d(c, heads * dim_head, 1)
         self.transformer_blocks = nn.ModuleList([BasicTransformerBlock(heads * dim_head, heads, dim_head, context_dim)])
-        self.proj_out = nn.Conv2d(heads * dim_head, c, 1)
+        self.proj_out = Conv2d(heads * dim_head, c, 1)
 
     def forward(self, x, context):
         b, c, h, w = x.shape
@@ -624,7 +674,7 @@ class SpatialTransformer(nn.Module):
 class UNetDownsample(nn.Module):
     def __init__(self, c):
         super().__init__()
-        self.op = nn.Conv2d(c, c, 3, stride=2, padding=1)
+        self.op = Conv2d(c, c, 3, stride=2, padding=1)
 
     def forward(self, x):
         return self.op(x)
@@ -633,7 +683,7 @@ class UNetDownsample(nn.Module):
 class UNetUpsample(nn.Module):
     def __init__(self, c):
         super().__init__()
-        self.conv = nn.Conv2d(c, c, 3, padding=1)
+        self.conv = Conv2d(c, c, 3, padding=1)
 
     def forward(self, x, defer_bias=False):
         if fused_conv_ok(x, self.conv, upsample=True):
@@ -665,7 +715,7 @@ class UNetModel(nn.Module):
         self.model_channels = model_channels
         emb = model_channels * 4
         self.time_embed = nn.Sequential(nn.Linear(model_channels, emb), nn.SiLU(), nn.Linear(emb, emb))
-        self.input_blocks = nn.ModuleList([TimestepSeq(nn.Conv2d(in_channels, model_channels, 3, padding=1))])
+        self.input_blocks = nn.ModuleList([TimestepSeq(Conv2d(in_channels, model_channels, 3, padding=1))])
         chans = [model_channels]
         ch, ds = model_channels, 1
         for level, mult in enumerate(channel_mult):
@@ -694,7 +744,7 @@ class UNetModel(nn.Module):
                     layers.append(UNetUpsample(ch))
                     ds //= 2
                 self.output_blocks.append(TimestepSeq(*layers))
-        self.out = nn.Sequential(group_norm(ch, 1e-5), nn.SiLU(), nn.Conv2d(model_channels, out_channels, 3, padding=1))
+        self.out = nn.Sequential(group_norm(ch, 1e-5), nn.SiLU(), Conv2d(model_channels, out_channels, 3, padding=1))
 
     def forward(self, x, timesteps, context, cond_emb=None, taps=(), stop_after_taps=False):
         """taps: indices of output_blocks whose (concatenated) input is recorded."""
