@@ -70,8 +70,14 @@ def own_conv(conv, x, with_bias=True, residual=None, padding=None):
     take: strided Downsample, the 16^2 / 8^2 UNet levels, 1x1 - or None when the call is not channels-last bf16 inference on a shape
     the kernel takes (the caller then uses torch).  padding: (top, left, bottom, right) overriding the module's symmetric padding
     (the VAE Downsample pads bottom / right only).  Unlike the library's split-K convolutions these are bit-reproducible."""
-    if _CONV_GEMM_LIBRARY or torch.is_grad_enabled() or not fused_nhwc(x) or x.dtype != torch.bfloat16 or conv.weight.dtype != torch.bfloat16:
+    if _CONV_GEMM_LIBRARY or torch.is_grad_enabled() or not fused_nhwc(x) or conv.weight.dtype != torch.bfloat16:
         return None
+    if x.dtype != torch.bfloat16:
+        # f32 activations into a bf16-weight convolution only happen under bf16 autocast (the trainable heads' inference): autocast
+        # itself would round x to bf16 here - do the same, one pass, and stay on the own kernel
+        if not (x.dtype == torch.float32 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16):
+            return None
+        x = x.to(torch.bfloat16)
     k = conv.kernel_size
     if not (k[0] == k[1] and k[0] <= 3 and conv.stride[0] == conv.stride[1] and conv.dilation == (1, 1) and conv.groups == 1
             and isinstance(conv.padding, tuple) and conv.in_channels % 64 == 0 and x.shape[1] == conv.in_channels):
@@ -83,18 +89,36 @@ def own_conv(conv, x, with_bias=True, residual=None, padding=None):
     return ops.conv_gemm(x, packed, tile, n32, conv.out_channels, k[0], conv.stride[0], pad, bias=bias if with_bias else None, residual=residual)
 
 
+_TRACE_LIBRARY_CONV = os.environ.get("XM3D_TRACE_CONV", "") == "1"  # diagnostic: name every convolution that still runs on the library
+_traced = set()
+
+
+def _trace_library_conv(conv, x):
+    key = (tuple(x.shape), str(x.dtype), tuple(conv.weight.shape), conv.stride, x.is_contiguous(memory_format=torch.channels_last) and not x.is_contiguous())
+    if key not in _traced:
+        _traced.add(key)
+        print(f"[xm3d] library convolution: x {key[0]} {key[1]} channels_last={key[4]} weight {key[2]} {conv.weight.dtype} stride {key[3]} "
+              f"grad={torch.is_grad_enabled()}", flush=True)
+
+
 class Conv2d(nn.Conv2d):
     """nn.Conv2d of the frozen nets: channels-last bf16 inference runs the own kernels (own_conv), everything else torch"""
 
     def forward(self, x):
         out = own_conv(self, x)
-        return out if out is not None else super().forward(x)
+        if out is not None:
+            return out
+        if _TRACE_LIBRARY_CONV:
+            _trace_library_conv(self, x)
+        return super().forward(x)
 
 
 def conv_nobias(conv: nn.Conv2d, x):
     out = own_conv(conv, x, with_bias=False)
     if out is not None:
         return out
+    if _TRACE_LIBRARY_CONV:
+        _trace_library_conv(conv, x)
     return F.conv2d(x, conv.weight, None, conv.stride, conv.padding, conv.dilation, conv.groups)
 
 
