@@ -517,35 +517,18 @@ def main():
             dense32_ms = event_ms(lambda: m32._dense_graphed(b32["img"], cond32), 3) / vb32
         fp32 = {"value": world * args.fp32_steps / dt32, "unit": "scenes/s", "ms_per_step": dt32 / args.fp32_steps * 1e3, "steps": args.fp32_steps,
                 "scenes_per_forward": G,
-                "dtype": "f32 everywhere (sparse 3D and the 3x3 ResnetBlock convolutions on bf16 split-operand MFMA kernels with f32 accumulation - "
-                         "two / three terms, <= 1e-6 per layer against f64; softmax attention = two library GEMMs around an aten softmax)",
+                "dtype": "f32 everywhere, on the 16-bit matrix cores: the sparse 3D convolutions (bf16 x 3 split operands), every dense convolution and "
+                         "GEMM of the frozen nets (two-term split in IEEE halves, three accumulating passes, f32 accumulation; <= 1e-6 per layer against f64); "
+                         "softmax attention = torch MATH (two library f32 GEMMs around an aten softmax)",
                 "roofline_dense_stage": {"bound": "mfma", "achieved": DENSE_TFLOP_PER_VIEW_MIN / (dense32_ms * 1e-3), "peak": FP32_MFMA_PEAK_TF,
                                          "unit": "TFLOP/s", "frac": DENSE_TFLOP_PER_VIEW_MIN / (dense32_ms * 1e-3) / FP32_MFMA_PEAK_TF,
                                          "ms_per_view": dense32_ms, "views_per_forward": vb32,
-                                         "scope": "dense 2D branch per view in f32 (3x3 ResnetBlock convolutions: six bf16 MFMA passes over three-term split operands; "
-                                                  "other convolutions / GEMMs: library, f32 matrix path)"}}
+                                         "scope": "dense 2D branch per view in f32 (convolutions / GEMMs of the frozen nets: three half-precision MFMA passes over "
+                                                  "two-term split operands; trainable heads' GEMMs and the attention products: library, f32 matrix path)"}}
         del b32, cond32
         del m32
         torch.cuda.empty_cache()
         log(f"fp32 configuration: {fp32['value']:.2f} scenes/s")
-        # the same configuration with the cheaper TWO-term operand split (three passes per convolution instead of six: ops.conv3x3_f32).
-        # Opt-in (XM3D_CONV_F32=hip): it spends most of the fp32 configuration's parity margin (per-point logits 6e-4 against the oracle
-        # instead of 1.5e-4; tests/test_gpu_bench_parity.py), hence reported beside, not as, fp32
-        try:
-            os.environ["XM3D_CONV_F32"] = "hip"  # two-term split
-            m32s = pipeline.make_inference_model(cpu_model, dev, torch.float32, channels_last=not args.nchw, graphs=True)
-            capture(m32s, args.fp32_steps, G)
-            run(m32s, G, G)
-            dts = timed(m32s, args.fp32_steps, G)
-            fp32["split_operand_convolutions"] = {
-                "value": world * args.fp32_steps / dts, "unit": "scenes/s", "ms_per_step": dts / args.fp32_steps * 1e3,
-                "note": "fp32 configuration with TWO-term split operands (three bf16 MFMA passes per convolution, 2e-5 per layer vs f64); per-point "
-                        "logits within 1e-3 of the oracle on the tested views but with a 1.7x margin instead of 6x: opt-in (XM3D_CONV_F32=hip)"}
-            del m32s
-            torch.cuda.empty_cache()
-            log(f"fp32 configuration, split-operand convolutions: {fp32['split_operand_convolutions']['value']:.2f} scenes/s")
-        finally:
-            os.environ.pop("XM3D_CONV_F32", None)
     out = None
 
     def finish(train):

@@ -272,6 +272,20 @@ int xm3d_split_bf16_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const
 int xm3d_conv3x3_nhwc_f32acc(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,
                              const float* bias, int32_t bias_bstride, const float* residual, float* out, double* stats_out, int32_t groups_out,
                              int32_t upsample, int32_t waves, void* stream);
+/* The same split in IEEE HALVES, the default of the fp32 configuration since round 4: two terms x = hi / s + lo / (2048 s) carry 22
+ * mantissa bits (three bf16 terms: 24, two: 16), so  conv(x, w) = [hi*whi] / (s t) + [hi*wlo + lo*whi] / (2048 s t)  is f32-exact to
+ * ~1e-6 in THREE passes instead of six (dropped: lo*wlo, 2^-22).  Both terms of an operand live at the magnitude of x * s - the half's
+ * narrow exponent range costs no bits; s, t are powers of two (exact), chosen so that |x| s <= 65504 (xm3d_split_f16_nhwc sets the
+ * sticky range flag beyond that: xm3d_check_flag).
+ *   xm3d_split_f16_nhwc       : as xm3d_split_bf16_nhwc, hi / lo are halves, scale_hi = s
+ *   xm3d_conv3x3_nhwc_f32acc2 : as xm3d_conv3x3_nhwc_f32acc with f16 = 1: x and wpacked hold halves (the packer only moves 16-bit
+ *                               words); out = residual + alpha * conv(x, w) + bias, alpha = the term pair's 1 / (scale product) */
+int xm3d_split_f16_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
+                        const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, float scale_hi, void* hi, void* lo,
+                        void* ws, void* stream);
+int xm3d_conv3x3_nhwc_f32acc2(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,
+                              const float* bias, int32_t bias_bstride, const float* residual, float* out, double* stats_out, int32_t groups_out,
+                              int32_t upsample, int32_t waves, int32_t f16, float alpha, void* stream);
 
 /* ---- linear layer / 1x1 convolution with fused epilogue (gemm.hip): the dense projections of the Stable-Diffusion UNet's
  * SpatialTransformer (to_q / to_k / to_v / to_out, GEGLU feed-forward, 1x1 proj_in / proj_out: models/modeling/meta_arch/ldm.py:425-446
@@ -313,6 +327,18 @@ int64_t xm3d_conv_gemm_ws_bytes(int64_t M, int32_t N, int32_t K, int32_t col_til
 int xm3d_conv_gemm_bf16(const void* x, int64_t B, int32_t Hin, int32_t Win, int32_t Cin, const void* wpacked, int32_t N, int32_t col_tile,
                         int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, const float* bias,
                         const void* residual, void* out, void* ws, void* stream);
+/* ---- f32-accurate GEMM / implicit-GEMM convolution (gemm.hip, GF_F16 | GF_OUT32): the fp32 configuration's Linear / 1x1 / strided /
+ * small-map convolutions (torch.nn.Linear / Conv2d in f32 in the reference: run/train.py:178 - no autocast) on the matrix cores, from
+ * operands split in IEEE halves as above:  x w = [xhi whi] / s + [xhi wlo + xlo whi] / (2048 s).  ONE pass per call:
+ *     out (f32) = act( alpha * (x_term @ W_term^T) + bias + accin ) + residual          act 0 none, 1 GELU, 2 QuickGELU
+ * x: (M, K) halves with row stride ldx - or, conv = 1, the channels-last image (B, Hin, Win, Cin) in halves, rows = output pixels as in
+ * xm3d_conv_gemm_bf16 (M = B*Ho*Wo, K = ksize*ksize*Cin); wpacked: xm3d_gemm_pack_weight of the half-valued term (16-bit words are
+ * moved unchanged); accin (M, N) f32 with row stride ldo (usually `out` itself) or NULL; residual (M, N) f32 row stride ldr or NULL.
+ * No atomics, no split-K: bit-reproducible. */
+int xm3d_gemm_f32acc(const void* x, int64_t M, int32_t K, int64_t ldx, const void* wpacked, int32_t N, int32_t col_tile, const float* bias, int32_t act,
+                     float alpha, const float* accin, const float* residual, int64_t ldr, float* out, int64_t ldo, int32_t waves, int32_t conv,
+                     int64_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho,
+                     int32_t Wo, void* stream);
 /* GroupNorm moments alone, in the layout the calls above take: stats[0 .. B*G*2) f64 <- (sum, sum of squares) of x (+ shift) per
  * (sample, group); x (B, H*W, C) channels-last, dtype 0 = f32 / 1 = bf16; stats holds xm3d_gn_stats_doubles_nhwc doubles. */
 int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,

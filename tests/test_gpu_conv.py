@@ -253,19 +253,21 @@ def test_conv3x3_cout_not_a_multiple_of_the_tile(dev, waves):
         assert out.shape == ref.shape and (out.float() - ref).abs().max().item() < 1e-2 * ref.abs().max().item()
 
 
-@pytest.mark.parametrize("waves,terms", [(8, 2), (4, 3), (8, 3)])
+@pytest.mark.parametrize("waves,terms", [(8, 2), (4, 3), (8, 3), (8, "f16"), (4, "f16")])
 @pytest.mark.parametrize("B,cin,cout,H,W,mode", [(2, 128, 128, 16, 64, "gn_res"), (1, 256, 512, 8, 32, "plain"), (2, 64, 256, 16, 64, "ups"),
                                                   (1, 320, 320, 8, 32, "gn_res"), (1, 512, 512, 16, 32, "gn_bias2")])
 def test_conv3x3_f32_accurate_form_matches_f64(dev, B, cin, cout, H, W, mode, waves, terms):
-    """ops.conv3x3_f32 (the fp32 configuration's convolution: split bf16 operands, three accumulating matrix-core passes) against an
-    f64 evaluation of the same layer.  Two-term split: bound 2e-5 of max|out| (the same bound as the split-operand sparse convolution);
-    three-term split (six passes): 4e-6, the level of an f32 library convolution's own rounding at K = 9 * 512."""
+    """ops.conv3x3_f32 (the fp32 configuration's convolution: split operands, accumulating matrix-core passes) against an f64 evaluation
+    of the same layer.  "f16" (the default): two terms in IEEE halves, three passes, bound 4e-6 - the level of an f32 library
+    convolution's own rounding at K = 9 * 512; three bf16 terms (six passes): the same bound; two bf16 terms: 2e-5."""
     from xmask3d_amd import ops
 
     g = torch.Generator().manual_seed(cin + 5 * cout + H + waves)
     G = 32
     hi_, wi_ = (H // 2, W // 2) if mode == "ups" else (H, W)
     x = _nhwc((torch.randn(B, cin, hi_, wi_, generator=g) * 1.3 + 0.4).to(dev))
+    if mode == "plain":  # un-normalised operands of very different magnitudes: the half's exponent range must not cost bits
+        x = _nhwc(x * torch.logspace(-4, 3, cin, device=dev).view(1, cin, 1, 1))
     w = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(dev)
     per_sample = mode == "gn_bias2"
     bias = (0.3 * torch.randn((B, cout) if per_sample else (cout,), generator=g)).to(dev)
@@ -294,3 +296,21 @@ def test_conv3x3_f32_accurate_form_matches_f64(dev, B, cin, cout, H, W, mode, wa
     err = (out.double() - ref).abs().max().item() / ref.abs().max().item()
     # two terms: dropped lo*lo and split residuals, 2^-18 each; three terms: the f32 accumulation of the partial sums is what is left
     assert err < (2e-5 if terms == 2 else 4e-6), err  # measured 3e-7 .. 1.1e-6 (K = 4608); an f32 library convolution: 1e-6 .. 5e-6
+    from xmask3d_amd._lib import lib
+
+    assert lib().xm3d_check_flag() == 0  # no operand left the half's range
+
+
+def test_f16_split_flags_operands_beyond_the_half_range(dev):
+    from xmask3d_amd import ops
+    from xmask3d_amd._lib import lib
+
+    x = _nhwc(torch.randn(1, 64, 8, 32, device=dev))
+    x[0, 3, 2, 5] = 1e7   # * 2^-6 > 65504
+    w = torch.randn(128, 64, 3, 3, device=dev) / 24
+    packs, tile = ops.conv3x3_pack_weight_split(w, "f16")
+    assert lib().xm3d_check_flag() == 0
+    ops.conv3x3_f32(x, packs, 128, tile)
+    torch.cuda.synchronize()
+    assert lib().xm3d_check_flag() != 0   # sticky range flag raised (and cleared by the query)
+    assert lib().xm3d_check_flag() == 0

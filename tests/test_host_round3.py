@@ -34,8 +34,8 @@ def test_hip_paths_refuse_cpu_tensors_and_autograd():
 
 def test_f32_convolution_switch(monkeypatch):
     monkeypatch.delenv("XM3D_CONV_F32", raising=False)
-    assert sd_model.conv_f32_terms() == 3          # default: three-term split, the f32-exact form
-    for val, terms in (("hip", 2), ("hip3", 3), ("library", 0), ("something", 0)):
+    assert sd_model.conv_f32_terms() == "f16"      # default: the two-term split in IEEE halves, three passes, f32-exact to ~1e-6
+    for val, terms in (("f16", "f16"), ("hip", 2), ("hip3", 3), ("library", 0), ("something", 0)):
         monkeypatch.setenv("XM3D_CONV_F32", val)
         assert sd_model.conv_f32_terms() == terms
 

@@ -70,6 +70,9 @@ _SIGS = {
     "xm3d_conv3x3_default_waves": (ctypes.c_int, [c_i32, c_i32, c_i32, c_i32]),
     "xm3d_split_bf16_nhwc": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_conv3x3_nhwc_f32acc": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp]),
+    "xm3d_split_f16_nhwc": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_i32, c_i32, ctypes.c_float, c_vp, c_vp, c_vp, c_vp]),
+    "xm3d_conv3x3_nhwc_f32acc2": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_vp, c_i32, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32,
+                                                 ctypes.c_float, c_vp]),
     "xm3d_gemm_col_tile": (ctypes.c_int, [c_i32]),
     "xm3d_gemm_packed_elems": (ctypes.c_int64, [c_i32, c_i32, c_i32]),
     "xm3d_gemm_pack_weight": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
@@ -78,6 +81,8 @@ _SIGS = {
     "xm3d_conv_gemm_ws_bytes": (ctypes.c_int64, [c_i64, c_i32, c_i32, c_i32]),
     "xm3d_conv_gemm_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp,
                                            c_vp, c_vp]),
+    "xm3d_gemm_f32acc": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, ctypes.c_float, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
+                                        c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "xm3d_group_norm_nhwc_stats": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_bias_residual_nhwc": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "xm3d_attn_mask_bias": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_i32, c_vp]),

@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
+from .sd_model import flinear, gemm_ok
 
 CLIP_MEAN = (0.48145466, 0.4578275, 0.40821073)
 CLIP_STD = (0.26862954, 0.26130258, 0.27577711)
@@ -55,7 +56,7 @@ class ResidualAttentionBlock(nn.Module):
     def attention(self, x, allow):
         """x (B,T,C); allow: None | bool (T,T) | bool (B,1,T,T), True = may attend."""
         b, t, c = x.shape
-        qkv = F.linear(x, self.attn.in_proj_weight, self.attn.in_proj_bias).view(b, t, 3, self.heads, c // self.heads)
+        qkv = flinear(x, self.attn.in_proj_weight, self.attn.in_proj_bias).view(b, t, 3, self.heads, c // self.heads)
         if ops.attention_supported(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]):
             # bf16 inference: HIP flash attention straight on the packed qkv buffer; `allow` as an additive mask (built once
             # per forward by the caller through additive_mask(), shared by the 24 layers)
@@ -63,14 +64,14 @@ class ResidualAttentionBlock(nn.Module):
             if bias is not None and bias.dim() == 2:
                 bias = bias[None, None]
             o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], bias=bias)
-            return self.attn.out_proj(o.view(b, t, c))
+            return flinear(o.view(b, t, c), self.attn.out_proj.weight, self.attn.out_proj.bias)
         q, k, v = qkv.permute(2, 0, 3, 1, 4)
         if allow is not None and allow.dtype != torch.bool:
             allow = allow.to(q.dtype)
             if allow.dim() == 2:
                 allow = allow[None, None]
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=allow)
-        return self.attn.out_proj(o.transpose(1, 2).reshape(b, t, c))
+        return flinear(o.transpose(1, 2).reshape(b, t, c), self.attn.out_proj.weight, self.attn.out_proj.bias)
 
     def forward(self, x, allow=None):
         n1, n2 = self.ln_1, self.ln_2
@@ -80,7 +81,14 @@ class ResidualAttentionBlock(nn.Module):
             h, x = ops.layer_norm(x, n2.weight, n2.bias, n2.eps, delta=a.contiguous(), want_sum=True)
             return x + self.mlp(h)
         x = x + self.attention(self.ln_1(x), allow)
-        return x + self.mlp(self.ln_2(x))
+        return self._mlp_res(self.ln_2(x), x)
+
+    def _mlp_res(self, h, x):
+        """x + c_proj(QuickGELU(c_fc(h))): on the own GEMM kernels - activation and residual in the epilogues - where gemm_ok() says so"""
+        fc, pj = self.mlp.c_fc, self.mlp.c_proj
+        if gemm_ok(h, fc.out_features, "quick_gelu") and gemm_ok(h, pj.out_features, None, True) and fc.weight.dtype == h.dtype:
+            return flinear(flinear(h, fc.weight, fc.bias, act="quick_gelu"), pj.weight, pj.bias, residual=x)
+        return x + self.mlp(h)
 
 
 class Transformer(nn.Module):

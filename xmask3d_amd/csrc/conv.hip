@@ -39,6 +39,7 @@ typedef __bf16 cv_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 cv_bf16x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 cv_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned cv_u32x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 cv_f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int CV_TW = 32;                            // output pixel tile: CV_TW columns x 8 or 4 rows of one image (ConvGeom)
 constexpr int CV_HW = CV_TW + 2;                     // halo tile width
@@ -65,6 +66,7 @@ struct ConvArgs {
     float2* stats_part;       // per-workgroup (sum, sum of squares) partials [b][cout tile][slot][pixel tile], or null (k_conv_stats_reduce)
     int B, H, W, cin, cout;
     int bias_bstride;
+    float alpha;              // F32OUT: out = residual + alpha * conv + bias (the power-of-two scale of a split term; 1 otherwise)
     int groups_out, cg_out, stat_slots;
     int tiles_x, tiles_y, nct;
 };
@@ -93,9 +95,11 @@ struct ConvGeom {
 // 3x3 convolution of detectron2's GroupNorm BottleneckBlock in the projection backbone, backbone/feature_extractor.py:20-60).
 // UPS: x has half the resolution, the operand is its nearest-neighbour 2x upsampling (ldm's Upsample -> conv).
 // F32OUT (plain convolutions only): `out` and `residual` are f32 - the accumulating form used by the f32-accurate convolution
-// (three bf16 passes over split operands, xm3d_conv3x3_nhwc_f32acc)
-template <int CT, int MODE, bool UPS, int NW, bool F32OUT>
+// (passes over split operands, xm3d_conv3x3_nhwc_f32acc).  F16 (F32OUT only): the operands are IEEE halves (v_mfma_f32_32x32x16_f16):
+// a two-term split in halves carries 22 mantissa bits, the same as three bf16 terms, in half the passes
+template <int CT, int MODE, bool UPS, int NW, bool F32OUT, bool F16 = false>
 __device__ __forceinline__ void conv3x3_body(const ConvArgs& a) {
+    static_assert(!F16 || (F32OUT && MODE == 0), "half operands: accumulating plain convolution only");
     using G = ConvGeom<CT, NW>;
     constexpr int TH = G::TH, HPIX = G::HPIX, ASZ = G::ASZ, PR = G::PR, ROUNDS = G::ROUNDS, MB = G::MB, NT = G::NT, NG = G::NG, D = G::D;
     constexpr int NGRP = 36 * NG;          // groups per chunk
@@ -270,6 +274,9 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a) {
 #pragma unroll
             for (int n = 0; n < 4; ++n) {
                 if (CV_ABL & 2) asm volatile("" ::"v"(wr[J % D][mb]), "v"(xf[xs & 1][n]));
+                else if constexpr (F16)
+                    acc[mb][half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(cv_f16x8, wr[J % D][mb]), __builtin_bit_cast(cv_f16x8, xf[xs & 1][n]),
+                                                                                   acc[mb][half * 4 + n], 0, 0, 0);
                 else acc[mb][half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wr[J % D][mb], xf[xs & 1][n], acc[mb][half * 4 + n], 0, 0, 0);
             }
             if (sub == NG - 1 && !(CV_ABL & 1)) {  // the ring slot is free: request the fragments of k-step J + D
@@ -339,8 +346,8 @@ __device__ __forceinline__ void conv3x3_body(const ConvArgs& a) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) {
                         float4 r = resf ? *reinterpret_cast<const float4*>(resf + o + 4 * q) : make_float4(0.f, 0.f, 0.f, 0.f);
-                        r.x += acc[m][n][4 * q] + bq[m][q].x, r.y += acc[m][n][4 * q + 1] + bq[m][q].y;
-                        r.z += acc[m][n][4 * q + 2] + bq[m][q].z, r.w += acc[m][n][4 * q + 3] + bq[m][q].w;
+                        r.x += fmaf(acc[m][n][4 * q], a.alpha, bq[m][q].x), r.y += fmaf(acc[m][n][4 * q + 1], a.alpha, bq[m][q].y);
+                        r.z += fmaf(acc[m][n][4 * q + 2], a.alpha, bq[m][q].z), r.w += fmaf(acc[m][n][4 * q + 3], a.alpha, bq[m][q].w);
                         *reinterpret_cast<float4*>(outf + o + 4 * q) = r;
                         gs[m][q] += (r.x + r.y) + (r.z + r.w);
                         gq[m][q] = fmaf(r.x, r.x, fmaf(r.y, r.y, fmaf(r.z, r.z, fmaf(r.w, r.w, gq[m][q]))));
@@ -451,15 +458,17 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3(const ConvArgs a) {
     conv3x3_body<CT, MODE, UPS, NW, false>(a);
 }
 
-template <int CT, bool UPS, int NW>
+template <int CT, bool UPS, int NW, bool F16>
 __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3_f32acc(const ConvArgs a) {
-    conv3x3_body<CT, 0, UPS, NW, true>(a);
+    conv3x3_body<CT, 0, UPS, NW, true, F16>(a);
 }
 
 // f32 (B, H*W, C) -> bf16 hi / lo with x = hi + lo (+ <= 2^-17 |x|), optionally through y = act(x * scale + shift) with the
 // per-(image, channel) GroupNorm affine of k_gn_affine: the operand split of the f32-accurate convolution.  One thread = 8 channels.
+// f16 (scale_hi > 0): hi = half(y * scale_hi), lo = half((y - hi / scale_hi) * scale_hi * 2^11): y = hi / s + lo / (s 2^11) to 2^-22 |y|; both terms
+// live at the magnitude of y * s, so neither loses bits to the half's narrow exponent range; values beyond 65504 / s set the range flag
 __global__ void k_split_nhwc(const float* __restrict__ x, const float* __restrict__ affine, int act, int64_t n8, int C, int64_t hw,
-                             __bf16* __restrict__ hi, __bf16* __restrict__ lo, __bf16* __restrict__ lo2) {
+                             __bf16* __restrict__ hi, __bf16* __restrict__ lo, __bf16* __restrict__ lo2, float scale_hi, int* __restrict__ flag) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n8) return;
     const int c8 = C / 8;
@@ -476,6 +485,22 @@ __global__ void k_split_nhwc(const float* __restrict__ x, const float* __restric
             else if (act == 2) y = fmaxf(y, 0.f);
             v[j] = y;
         }
+    }
+    if (scale_hi > 0.f) {
+        cv_f16x8 h8, l8;
+        const float inv = 1.f / scale_hi, sl = scale_hi * 2048.f;  // powers of two: exact
+        bool bad = false;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float t = v[j] * scale_hi;
+            bad |= !(fabsf(t) <= 65504.f);
+            h8[j] = (_Float16)t;
+            l8[j] = (_Float16)((v[j] - float(h8[j]) * inv) * sl);
+        }
+        if (bad) *flag = XM3D_ERANGE;
+        *reinterpret_cast<cv_f16x8*>(hi + i * 8) = h8;
+        *reinterpret_cast<cv_f16x8*>(lo + i * 8) = l8;
+        return;
     }
     cv_bf16x8 h8, l8, m8;
 #pragma unroll
@@ -545,17 +570,22 @@ static int launch_conv(const ConvArgs& a, hipStream_t s) {
     return XM3D_OK;
 }
 
-template <int CT, bool UPS, int NW>
-static int launch_conv_f32acc(const ConvArgs& a, hipStream_t s) {
+template <int CT, bool UPS, int NW, bool F16>
+static int launch_conv_f32acc_t(const ConvArgs& a, hipStream_t s) {
     using G = ConvGeom<CT, NW>;
     static DeviceOnce configured;  // the attribute is per device
     if (configured.first()) {
-        XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_f32acc<CT, UPS, NW>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
+        XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv3x3_f32acc<CT, UPS, NW, F16>), hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS));
     }
     const int grid = a.B * a.tiles_y * a.tiles_x * a.nct;
-    hipLaunchKernelGGL((k_conv3x3_f32acc<CT, UPS, NW>), dim3(grid), dim3(G::NTH), G::LDS, s, a);
+    hipLaunchKernelGGL((k_conv3x3_f32acc<CT, UPS, NW, F16>), dim3(grid), dim3(G::NTH), G::LDS, s, a);
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
+}
+
+template <int CT, bool UPS, int NW>
+static int launch_conv_f32acc(const ConvArgs& a, bool f16, hipStream_t s) {
+    return f16 ? launch_conv_f32acc_t<CT, UPS, NW, true>(a, s) : launch_conv_f32acc_t<CT, UPS, NW, false>(a, s);
 }
 
 template <int CT, int NW>
@@ -686,6 +716,7 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
     a.cin = cin;
     a.cout = cout;
     a.bias_bstride = bias_bstride;
+    a.alpha = 1.f;
     a.tiles_x = W / CV_TW;
     a.tiles_y = H / TH;
     a.nct = (cout + cout_tile - 1) / cout_tile;
@@ -699,9 +730,9 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
 // ---- f32-accurate convolution from three bf16 passes over split operands:  x = x_hi + x_lo, w = w_hi + w_lo (bf16 each),
 //      conv(x, w) ~= conv(x_hi, w_hi) + conv(x_hi, w_lo) + conv(x_lo, w_hi)   (the dropped x_lo * w_lo and the split residuals are
 //      <= 2^-16 |x w| each), f32 accumulation across the passes in the f32 output tensor.
-extern "C" int xm3d_split_bf16_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
-                                    const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, void* hi, void* lo,
-                                    void* lo2, void* ws, void* stream) {
+static int split_nhwc_impl(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
+                           const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, void* hi, void* lo,
+                           void* lo2, float scale_hi, void* ws, void* stream) {
     XM3D_REQUIRE(x && hi && lo, "split_bf16_nhwc: null pointer");
     XM3D_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0, "split_bf16_nhwc: C %d must be a multiple of 8", C);
     XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15) == 0,
@@ -720,15 +751,41 @@ extern "C" int xm3d_split_bf16_nhwc(const float* x, int64_t B, int64_t HW, int32
     }
     const int64_t n8 = B * HW * (C / 8);
     hipLaunchKernelGGL(k_split_nhwc, dim3(unsigned((n8 + 255) / 256)), dim3(256), 0, s, x, affine, act, n8, C, HW, static_cast<__bf16*>(hi),
-                       static_cast<__bf16*>(lo), static_cast<__bf16*>(lo2));
+                       static_cast<__bf16*>(lo), static_cast<__bf16*>(lo2), scale_hi, device_flag());
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
 
+extern "C" int xm3d_split_bf16_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
+                                    const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, void* hi, void* lo,
+                                    void* lo2, void* ws, void* stream) {
+    return split_nhwc_impl(x, B, HW, C, gn_stats, gamma, beta, in_shift, in_shift_bstride, eps, groups, act, hi, lo, lo2, 0.f, ws, stream);
+}
+
+// the two-term split in IEEE halves: y = hi / scale_hi + lo / (scale_hi * 2048), |y - (..)| <= 2^-22 |y| (see k_split_nhwc); scale_hi a power
+// of two such that |y| * scale_hi <= 65504 (larger values set the sticky range flag, xm3d_check_flag)
+extern "C" int xm3d_split_f16_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
+                                   const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, float scale_hi, void* hi,
+                                   void* lo, void* ws, void* stream) {
+    XM3D_REQUIRE(scale_hi > 0.f, "split_f16_nhwc: scale_hi must be positive");
+    return split_nhwc_impl(x, B, HW, C, gn_stats, gamma, beta, in_shift, in_shift_bstride, eps, groups, act, hi, lo, nullptr, scale_hi, ws, stream);
+}
+
 // out (f32) = conv3x3(x bf16, w bf16 packed) + bias + residual (f32; may be `out` itself: accumulate in place)
+extern "C" int xm3d_conv3x3_nhwc_f32acc2(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,
+                                         const float* bias, int32_t bias_bstride, const float* residual, float* out, double* stats_out,
+                                         int32_t groups_out, int32_t upsample, int32_t waves, int32_t f16, float alpha, void* stream);
+
 extern "C" int xm3d_conv3x3_nhwc_f32acc(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,
                                         const float* bias, int32_t bias_bstride, const float* residual, float* out, double* stats_out,
                                         int32_t groups_out, int32_t upsample, int32_t waves, void* stream) {
+    return xm3d_conv3x3_nhwc_f32acc2(x, B, H, W, cin, wpacked, cout, cout_tile, bias, bias_bstride, residual, out, stats_out, groups_out, upsample, waves, 0, 1.f, stream);
+}
+
+// ... with the operands in IEEE halves (f16 = 1) and the product scaled by alpha before it is added: out = residual + alpha * conv(x, w) + bias
+extern "C" int xm3d_conv3x3_nhwc_f32acc2(const void* x, int64_t B, int32_t H, int32_t W, int32_t cin, const void* wpacked, int32_t cout, int32_t cout_tile,
+                                         const float* bias, int32_t bias_bstride, const float* residual, float* out, double* stats_out,
+                                         int32_t groups_out, int32_t upsample, int32_t waves, int32_t f16, float alpha, void* stream) {
     XM3D_REQUIRE(x && wpacked && out, "conv3x3_nhwc_f32acc: null pointer");
     XM3D_REQUIRE(waves == 0 || waves == 4 || waves == 8, "conv3x3_nhwc_f32acc: waves must be 0 (auto), 4 or 8");
     if (waves == 0) waves = xm3d_conv3x3_default_waves(H, W, cin, cout);
@@ -755,15 +812,17 @@ extern "C" int xm3d_conv3x3_nhwc_f32acc(const void* x, int64_t B, int32_t H, int
     conv_stats_setup(a, stats_out, B, cout, cout_tile, groups_out);
     a.B = int(B), a.H = H, a.W = W, a.cin = cin, a.cout = cout;
     a.bias_bstride = bias_bstride;
+    a.alpha = alpha;
     a.tiles_x = W / CV_TW;
     a.tiles_y = H / TH;
     a.nct = (cout + cout_tile - 1) / cout_tile;
     hipStream_t s = as_stream(stream);
+    const bool h = f16 != 0;
     int rc;
     if (cout_tile == 256) {
-        if (waves == 8) rc = upsample ? launch_conv_f32acc<256, true, 8>(a, s) : launch_conv_f32acc<256, false, 8>(a, s);
-        else rc = upsample ? launch_conv_f32acc<256, true, 4>(a, s) : launch_conv_f32acc<256, false, 4>(a, s);
-    } else if (waves == 8) rc = upsample ? launch_conv_f32acc<128, true, 8>(a, s) : launch_conv_f32acc<128, false, 8>(a, s);
-    else rc = upsample ? launch_conv_f32acc<128, true, 4>(a, s) : launch_conv_f32acc<128, false, 4>(a, s);
+        if (waves == 8) rc = upsample ? launch_conv_f32acc<256, true, 8>(a, h, s) : launch_conv_f32acc<256, false, 8>(a, h, s);
+        else rc = upsample ? launch_conv_f32acc<256, true, 4>(a, h, s) : launch_conv_f32acc<256, false, 4>(a, h, s);
+    } else if (waves == 8) rc = upsample ? launch_conv_f32acc<128, true, 8>(a, h, s) : launch_conv_f32acc<128, false, 8>(a, h, s);
+    else rc = upsample ? launch_conv_f32acc<128, true, 4>(a, h, s) : launch_conv_f32acc<128, false, 4>(a, h, s);
     return rc != XM3D_OK ? rc : conv_stats_finish(a, stats_out, cout_tile, s);
 }

@@ -51,6 +51,7 @@ struct GemmArgs {
     const __bf16* residual;  // (M, N_out), row stride ldr, or null (GF_OUT32: f32)
     __bf16* out;             // (M, N_out), row stride ldo (GF_OUT32: f32; split-K: slab blockIdx.y at + blockIdx.y * M * ldo)
     const float* accin;      // GF_OUT32: (M, N_out) f32, row stride ldo, added BEFORE the activation (accumulating passes), or null
+    float alpha;             // GF_OUT32: the product is scaled by alpha (the power-of-two scale of a split term pair) before anything is added
     int M, K, N;             // N = rows of W (GEGLU: 2 N_out)
     int ldx, ldr, ldo;
     int nct;                 // column tiles
@@ -327,7 +328,8 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
                 if (row >= M) continue;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
-                    float v[4] = {acc[n][4 * q] + bq[q].x, acc[n][4 * q + 1] + bq[q].y, acc[n][4 * q + 2] + bq[q].z, acc[n][4 * q + 3] + bq[q].w};
+                    float v[4] = {fmaf(acc[n][4 * q], a.alpha, bq[q].x), fmaf(acc[n][4 * q + 1], a.alpha, bq[q].y), fmaf(acc[n][4 * q + 2], a.alpha, bq[q].z),
+                                  fmaf(acc[n][4 * q + 3], a.alpha, bq[q].w)};
                     if (a.accin) {
                         const float4 t = *reinterpret_cast<const float4*>(a.accin + int64_t(row) * a.ldo + col + 4 * q);
                         v[0] += t.x, v[1] += t.y, v[2] += t.z, v[3] += t.w;
@@ -560,6 +562,7 @@ extern "C" int xm3d_gemm_bf16(const void* x, int64_t M, int K, int64_t ldx, cons
     a.residual = static_cast<const __bf16*>(residual);
     a.out = static_cast<__bf16*>(out);
     a.accin = nullptr;
+    a.alpha = 1.f;
     a.M = int(M), a.K = K, a.N = N;
     a.ldx = int(ldx), a.ldr = int(ldr), a.ldo = int(ldo);
     a.nct = (N + col_tile - 1) / col_tile;
@@ -611,6 +614,7 @@ extern "C" int xm3d_conv_gemm_bf16(const void* x, int64_t B, int32_t Hin, int32_
     a.x = static_cast<const __bf16*>(x);
     a.wp = static_cast<const __bf16*>(wpacked);
     a.accin = nullptr;
+    a.alpha = 1.f;
     a.M = int(M), a.K = ksize * ksize * Cin, a.N = N;
     a.ldx = 0, a.ldr = N, a.ldo = N;
     a.Hin = Hin, a.Win = Win, a.Cin = Cin, a.Ho = Ho, a.Wo = Wo, a.stride = stride, a.pad_t = pad_t, a.pad_l = pad_l, a.ksz = ksize;
@@ -636,4 +640,60 @@ extern "C" int xm3d_conv_gemm_bf16(const void* x, int64_t B, int32_t Hin, int32_
                        static_cast<const __bf16*>(residual), int64_t(N), static_cast<__bf16*>(out), int64_t(N));
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
+}
+
+// ---- f32-accurate GEMM / implicit-GEMM convolution from matrix-core passes over operands split in IEEE halves (GF_F16 | GF_OUT32):
+//   x = xhi / s + xlo / (2048 s), w = whi + wlo / 2048   ->   x w = [xhi whi] / s + [xhi wlo + xlo whi] / (2048 s)  (+ 2^-22 |x w|)
+// ONE pass: out (f32) = act(alpha * (x_term @ W_term^T) + bias + accin) + residual.  The caller runs the three term pairs with
+// accin = out (xmask3d_amd.ops.gemm_f32 / conv_gemm_f32).  x: (M, K) halves, row stride ldx (conv = 0), or the channels-last image
+// (B, Hin, Win, Cin) in halves (conv = 1: geometry as xm3d_conv_gemm_bf16, M = B * Ho * Wo, no split-K).
+extern "C" int xm3d_gemm_f32acc(const void* x, int64_t M, int32_t K, int64_t ldx, const void* wpacked, int32_t N, int32_t col_tile, const float* bias,
+                                int32_t act, float alpha, const float* accin, const float* residual, int64_t ldr, float* out, int64_t ldo, int32_t waves,
+                                int32_t conv, int64_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t,
+                                int32_t pad_l, int32_t Ho, int32_t Wo, void* stream) {
+    XM3D_REQUIRE(x && wpacked && out, "gemm_f32acc: null pointer");
+    XM3D_REQUIRE(col_tile == 128 || col_tile == 256, "gemm_f32acc: column tile %d unsupported", col_tile);
+    XM3D_REQUIRE(N > 0 && N % 32 == 0, "gemm_f32acc: N %d is not a multiple of 32", N);
+    XM3D_REQUIRE(act >= 0 && act <= 2, "gemm_f32acc: epilogue %d unsupported (none, GELU, QuickGELU)", act);
+    GemmArgs a;
+    if (conv) {
+        XM3D_REQUIRE(B > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cin % GM_KC == 0, "gemm_f32acc: bad convolution shape (Cin %d)", Cin);
+        XM3D_REQUIRE(ksize >= 1 && ksize <= 3 && stride >= 1 && pad_t >= 0 && pad_l >= 0 && pad_t < ksize && pad_l < ksize, "gemm_f32acc: kernel size 1..3, padding < kernel size");
+        XM3D_REQUIRE((Ho - 1) * stride - pad_t < Hin && (Wo - 1) * stride - pad_l < Win, "gemm_f32acc: output %dx%d reaches outside the input", Ho, Wo);
+        XM3D_REQUIRE(M == B * Ho * Wo && K == ksize * ksize * Cin && B * Hin * Win * Cin < (int64_t(1) << 31), "gemm_f32acc: M / K do not match the convolution");
+        XM3D_REQUIRE(act == 0, "gemm_f32acc: the convolution form has no activation");
+    } else {
+        XM3D_REQUIRE(K > 0 && K % GM_KC == 0 && ldx >= K && ldx % 8 == 0 && M * ldx < (int64_t(1) << 31), "gemm_f32acc: K %d / ldx unsupported", K);
+    }
+    XM3D_REQUIRE(M > 0 && M < (int64_t(1) << 31) - GM_MT && M * ldo < (int64_t(1) << 31), "gemm_f32acc: M out of range (32-bit offsets)");
+    XM3D_REQUIRE(ldo >= N && ldo % 4 == 0 && (!residual || (ldr >= N && ldr % 4 == 0)), "gemm_f32acc: row strides must cover the row (multiples of 4)");
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(wpacked) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(accin) |
+                   reinterpret_cast<uintptr_t>(residual) | reinterpret_cast<uintptr_t>(bias)) & 15) == 0,
+                 "gemm_f32acc: tensors must be 16-byte aligned");
+    a.x = static_cast<const __bf16*>(x);
+    a.wp = static_cast<const __bf16*>(wpacked);
+    a.bias = bias;
+    a.residual = reinterpret_cast<const __bf16*>(residual);
+    a.out = reinterpret_cast<__bf16*>(out);
+    a.accin = accin;
+    a.alpha = alpha;
+    a.M = int(M), a.K = K, a.N = N;
+    a.ldx = int(ldx), a.ldr = int(ldr), a.ldo = int(ldo);
+    a.Hin = Hin, a.Win = Win, a.Cin = Cin, a.Ho = Ho, a.Wo = Wo, a.stride = stride, a.pad_t = pad_t, a.pad_l = pad_l, a.ksz = ksize;
+    int tile = col_tile;
+    if (tile == 256 && ((M + 255) / 256) * ((N + 255) / 256) < 200) tile = 128;
+    XM3D_REQUIRE(waves == 0 || waves == 8 || (waves == 4 && tile == 128), "gemm_f32acc: waves must be 0 (choose), 8, or 4 with column tile 128");
+    if (waves == 0) waves = tile == 128 ? xm3d_gemm_default_waves(M, N, 128) : 8;
+    a.nct = (N + tile - 1) / tile;
+    hipStream_t s = as_stream(stream);
+    constexpr int FG = GF_F16 | GF_OUT32, FC = GF_F16 | GF_OUT32 | GF_CONV;
+    if (conv) return tile == 256 ? launch_gemm<256, GM_ACT_NONE, FC>(a, waves, 1, s) : launch_gemm<128, GM_ACT_NONE, FC>(a, waves, 1, s);
+    if (tile == 256) {
+        if (act == GM_ACT_GELU) return launch_gemm<256, GM_ACT_GELU, FG>(a, waves, 1, s);
+        if (act == GM_ACT_QUICK_GELU) return launch_gemm<256, GM_ACT_QUICK_GELU, FG>(a, waves, 1, s);
+        return launch_gemm<256, GM_ACT_NONE, FG>(a, waves, 1, s);
+    }
+    if (act == GM_ACT_GELU) return launch_gemm<128, GM_ACT_GELU, FG>(a, waves, 1, s);
+    if (act == GM_ACT_QUICK_GELU) return launch_gemm<128, GM_ACT_QUICK_GELU, FG>(a, waves, 1, s);
+    return launch_gemm<128, GM_ACT_NONE, FG>(a, waves, 1, s);
 }

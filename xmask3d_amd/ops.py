@@ -510,8 +510,9 @@ def conv3x3_pack_weight(weight):
     tile = lib().xm3d_conv3x3_cout_tile(cout)
     if tile == 0 or cin % 64 != 0 or tuple(weight.shape[2:]) != (3, 3):
         raise TypeError(f"conv3x3_pack_weight: unsupported weight shape {tuple(weight.shape)}")
-    w = weight.detach().to(torch.bfloat16).permute(0, 2, 3, 1).contiguous()  # OHWI
-    packed = torch.empty(lib().xm3d_conv3x3_packed_elems(cout, cin, tile), dtype=torch.bfloat16, device=w.device)
+    dt = torch.float16 if weight.dtype == torch.float16 else torch.bfloat16  # halves: a term of the f32-accurate split (the packer moves 16-bit words)
+    w = weight.detach().to(dt).permute(0, 2, 3, 1).contiguous()  # OHWI
+    packed = torch.empty(lib().xm3d_conv3x3_packed_elems(cout, cin, tile), dtype=dt, device=w.device)
     check(lib().xm3d_conv3x3_pack_weight(_ptr(w), cout, cin, tile, _ptr(packed), _stream()), "xm3d_conv3x3_pack_weight")
     return packed, tile
 
@@ -526,9 +527,26 @@ def conv3x3_f32_supported(x, cout, upsample=False):
     return H % 4 == 0 and W % 32 == 0 and cin % 64 == 0 and cout % 32 == 0 and cout >= 128
 
 
+F16_LO_SCALE = 2048.0   # the second term of a split in halves is stored times 2^11 (both terms at one magnitude)
+F16_X_SCALE = 2.0 ** -6  # activations are split as hi = half(x * 2^-6): |x| up to 4.2e6 before the half overflows (flagged by the kernel)
+
+
+def split_f16(t, scale_hi=1.0):
+    """f32 tensor -> (hi, lo) halves with t = hi / scale_hi + lo / (scale_hi * 2048) to 2^-22 |t| (torch ops; weights, once)"""
+    t = t.detach().float()
+    hi = (t * scale_hi).to(torch.float16)
+    lo = ((t - hi.float() / scale_hi) * (scale_hi * F16_LO_SCALE)).to(torch.float16)
+    return hi, lo
+
+
 def conv3x3_pack_weight_split(weight, terms=3):
     """f32 Conv2d weight (cout, cin, 3, 3) -> ([packed term 0, 1(, 2)], cout tile): the bf16 split w = t0 + t1 (+ t2) of the f32-accurate
-    convolution (two terms: 2^-18 |w| left over; three: 2^-25)"""
+    convolution (two terms: 2^-18 |w| left over; three: 2^-25); terms = "f16": the two-term split in halves (split_f16: 2^-22)"""
+    if terms == "f16":
+        hi, lo = split_f16(weight)
+        p0, tile = conv3x3_pack_weight(hi)
+        p1, _ = conv3x3_pack_weight(lo)
+        return [p0, p1], tile
     r = weight.detach().float()
     packs, tile = [], None
     for _ in range(terms):
@@ -542,14 +560,16 @@ def conv3x3_pack_weight_split(weight, terms=3):
 def conv3x3_f32(x, packs, cout, tile, bias=None, gn=None, residual=None, stats_groups=None, upsample=False, in_shift=None, waves=0):
     """conv3x3(act(GroupNorm(x))) + bias (+ residual) on channels-last f32 tensors, to f32 accuracy, on the bf16 matrix cores: one split
     pass (x -> bf16 terms, the GroupNorm affine + activation applied on the way) and accumulating convolution launches over the
-    term pairs - len(packs) == 2: x0 w0 + x0 w1 + x1 w0 (2e-5 of max|out|); 3: + x0 w2 + x2 w0 + x1 w1 (~1e-6, the rounding level of an
-    f32 convolution).  Arguments as conv3x3; bias / residual / result f32."""
+    term pairs - packs in halves (conv3x3_pack_weight_split(w, "f16"), the default): two terms of 11 bits each, three passes, ~1e-6 (the
+    rounding level of an f32 convolution); bf16 packs: len(packs) == 2: x0 w0 + x0 w1 + x1 w0 (2e-5 of max|out|); 3: + x0 w2 + x2 w0 + x1 w1
+    (~1e-6 in six passes).  Arguments as conv3x3; bias / residual / result f32."""
     if not conv3x3_f32_supported(x, cout, upsample):
         raise TypeError(f"conv3x3_f32: unsupported input {tuple(x.shape)} {x.dtype}")
+    f16 = packs[0].dtype == torch.float16
     terms = len(packs)
     B, cin, Hi, Wi = x.shape
     H, W = (2 * Hi, 2 * Wi) if upsample else (Hi, Wi)
-    xt = [torch.empty((B, cin, Hi, Wi), dtype=torch.bfloat16, device=x.device, memory_format=torch.channels_last) for _ in range(terms)]
+    xt = [torch.empty((B, cin, Hi, Wi), dtype=packs[0].dtype, device=x.device, memory_format=torch.channels_last) for _ in range(terms)]
     stats_in = gamma = beta = ws = None
     eps, G, act, sstride = 0.0, 0, 0, 0
     if gn is not None:
@@ -560,8 +580,12 @@ def conv3x3_f32(x, packs, cout, tile, bias=None, gn=None, residual=None, stats_g
             sstride = cin if (in_shift.numel() == B * cin and B > 1) else 0
     elif in_shift is not None:
         raise TypeError("conv3x3_f32: in_shift needs gn")
-    check(lib().xm3d_split_bf16_nhwc(_ptr(x), B, Hi * Wi, cin, _ptr(stats_in), _ptr(gamma), _ptr(beta), _ptr(in_shift), sstride, float(eps), int(G), act,
-                                     _ptr(xt[0]), _ptr(xt[1]), _ptr(xt[2]) if terms == 3 else None, _ptr(ws), _stream()), "xm3d_split_bf16_nhwc")
+    if f16:
+        check(lib().xm3d_split_f16_nhwc(_ptr(x), B, Hi * Wi, cin, _ptr(stats_in), _ptr(gamma), _ptr(beta), _ptr(in_shift), sstride, float(eps), int(G), act,
+                                        F16_X_SCALE, _ptr(xt[0]), _ptr(xt[1]), _ptr(ws), _stream()), "xm3d_split_f16_nhwc")
+    else:
+        check(lib().xm3d_split_bf16_nhwc(_ptr(x), B, Hi * Wi, cin, _ptr(stats_in), _ptr(gamma), _ptr(beta), _ptr(in_shift), sstride, float(eps), int(G), act,
+                                         _ptr(xt[0]), _ptr(xt[1]), _ptr(xt[2]) if terms == 3 else None, _ptr(ws), _stream()), "xm3d_split_bf16_nhwc")
     out = torch.empty((B, cout, H, W), dtype=torch.float32, device=x.device, memory_format=torch.channels_last)
     bstride = 0
     if bias is not None:
@@ -573,13 +597,18 @@ def conv3x3_f32(x, packs, cout, tile, bias=None, gn=None, residual=None, stats_g
     u, wv = int(bool(upsample)), int(waves) or _CONV_WAVES
     stats_out = torch.empty(lib().xm3d_conv3x3_stats_doubles(B, H, W, cout, tile, int(stats_groups), wv), dtype=torch.float64,
                             device=x.device) if stats_groups else None
-    L = lib().xm3d_conv3x3_nhwc_f32acc
-    pairs = [(0, 0), (0, 1), (1, 0)] + ([(0, 2), (2, 0), (1, 1)] if terms == 3 else [])
-    for n, (i, j) in enumerate(pairs):
+    L = lib().xm3d_conv3x3_nhwc_f32acc2
+    if f16:
+        # (x term, w term, alpha): the two small products first, the leading one last (statistics of the final values in its epilogue)
+        a_small = 1.0 / (F16_X_SCALE * F16_LO_SCALE)
+        pairs = [(0, 1, a_small), (1, 0, a_small), (0, 0, 1.0 / F16_X_SCALE)]
+    else:
+        pairs = [(0, 0, 1.0), (0, 1, 1.0), (1, 0, 1.0)] + ([(0, 2, 1.0), (2, 0, 1.0), (1, 1, 1.0)] if terms == 3 else [])
+    for n, (i, j, alpha) in enumerate(pairs):
         first, last = n == 0, n == len(pairs) - 1
         check(L(_ptr(xt[i]), B, H, W, cin, _ptr(packs[j]), cout, tile, _ptr(bias) if first else None, bstride if first else 0,
                 _ptr(residual) if first else _ptr(out), _ptr(out), _ptr(stats_out) if last else None, int(stats_groups or 0) if last else 0, u, wv,
-                _stream()), "xm3d_conv3x3_nhwc_f32acc")
+                int(f16), float(alpha), _stream()), "xm3d_conv3x3_nhwc_f32acc2")
     if stats_out is not None:
         out._xm3d_gn_stats = (stats_out[:B * stats_groups * 2], int(stats_groups), out.data_ptr())
     return out
@@ -690,6 +719,102 @@ def conv_gemm(x, packed, tile, n32, cout, ksize, stride=1, padding=(0, 0, 0, 0),
     ws = torch.empty(nb // 4, dtype=torch.float32, device=x.device) if nb else None
     check(lib().xm3d_conv_gemm_bf16(_ptr(x), B, H, W, cin, _ptr(packed), n32, tile, ksize, stride, pt, pl, Ho, Wo, _ptr(bias), _ptr(residual), _ptr(out),
                                     _ptr(ws), _stream()), "xm3d_conv_gemm_bf16")
+    img = out.permute(0, 3, 1, 2)
+    return img if n32 == cout else img[:, :cout].contiguous(memory_format=torch.channels_last)
+
+
+# ---- f32-accurate GEMM / implicit-GEMM convolution: three matrix-core passes over operands split in IEEE halves (xm3d_gemm_f32acc)
+def gemm_pack_weight_f16(weight):
+    """f32 Linear / Conv2d weight (N, K) or (N, cin, k, k) -> ([packed hi, packed lo], column tile, padded N): the two-term split in
+    halves (split_f16); convolution weights go in (ky, kx, cin) order, N is padded with zero rows to a multiple of 32"""
+    w = weight.detach().float()
+    if w.dim() == 4:
+        w = w.permute(0, 2, 3, 1)
+    w = w.reshape(w.shape[0], -1)
+    n32 = (w.shape[0] + 31) // 32 * 32
+    if n32 != w.shape[0]:
+        w = torch.cat([w, torch.zeros(n32 - w.shape[0], w.shape[1], dtype=w.dtype, device=w.device)])
+    packs, tile = [], None
+    for t in split_f16(w):
+        # the packer moves 16-bit words (its bf16 -> f32 -> bf16 round trip is the identity on them)
+        p_, tile = gemm_pack_weight(t.contiguous().view(torch.bfloat16))
+        packs.append(p_)
+    return packs, tile, n32
+
+
+def _split_rows_f16(x2):
+    """(M, K) contiguous f32 -> (hi, lo) halves at F16_X_SCALE (one pass)"""
+    m, k = x2.shape
+    hi, lo = torch.empty((m, k), dtype=torch.float16, device=x2.device), torch.empty((m, k), dtype=torch.float16, device=x2.device)
+    check(lib().xm3d_split_f16_nhwc(_ptr(x2), 1, m, k, None, None, None, None, 0, 0.0, 0, 0, F16_X_SCALE, _ptr(hi), _ptr(lo), None, _stream()),
+          "xm3d_split_f16_nhwc")
+    return hi, lo
+
+
+def _f32acc_passes(L_args, terms, packs, out, bias, act, residual, ldr):
+    """the three term pairs of x w: small products first, the leading one - with the activation and the residual - last"""
+    a_small = 1.0 / (F16_X_SCALE * F16_LO_SCALE)
+    for n, (i, j, alpha) in enumerate(((0, 1, a_small), (1, 0, a_small), (0, 0, 1.0 / F16_X_SCALE))):
+        first, last = n == 0, n == 2
+        L_args(terms[i], packs[j], _ptr(bias) if first else None, GEMM_ACTS[act] if last else 0, float(alpha), None if first else _ptr(out),
+               _ptr(residual) if last else None, ldr)
+
+
+def gemm_f32(x, packs, n, tile, bias=None, act=None, residual=None):
+    """act(x @ W^T + bias) (+ residual) over the last dimension of an f32 tensor, to f32 accuracy (~1e-6), on the matrix cores.
+    packs: gemm_pack_weight_f16(W); n: its (padded) row count; act None | "gelu" | "quick_gelu"; bias f32 (n); residual f32 like the output."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 64 == 0):
+        raise TypeError(f"gemm_f32: f32 device tensor with K % 64 == 0 required, got {tuple(x.shape)} {x.dtype}")
+    k = x.shape[-1]
+    x2 = x.reshape(-1, k)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    m = x2.shape[0]
+    terms = _split_rows_f16(x2)
+    out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
+    ldr = 0
+    if residual is not None:
+        if residual.dtype != torch.float32 or residual.shape != out.shape or not residual.is_contiguous():
+            raise TypeError("gemm_f32: residual must be a contiguous f32 tensor of the output's shape")
+        ldr = n
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != n):
+        raise TypeError("gemm_f32: bias must be a contiguous f32 (n,) tensor")
+
+    def run(xt, wp, b, a, alpha, accin, res, ldr_):
+        check(lib().xm3d_gemm_f32acc(_ptr(xt), m, k, k, _ptr(wp), n, tile, b, a, alpha, accin, res, ldr_, _ptr(out), n, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0,
+                                     _stream()), "xm3d_gemm_f32acc")
+
+    _f32acc_passes(run, terms, packs, out, bias, act, residual, ldr)
+    return out
+
+
+def conv_gemm_f32(x, packs, tile, n32, cout, ksize, stride=1, padding=(0, 0, 0, 0), bias=None, residual=None):
+    """conv2d(x, W, stride, zero padding (top, left, bottom, right)) + bias (+ residual) on a channels-last f32 image, to f32 accuracy:
+    the implicit-GEMM kernel over operands split in halves (three passes).  packs: gemm_pack_weight_f16(W)."""
+    if not (is_nhwc(x) and x.dtype == torch.float32 and x.shape[1] % 64 == 0):
+        raise TypeError(f"conv_gemm_f32: channels-last f32 device tensor with cin % 64 == 0 required, got {tuple(x.shape)} {x.dtype}")
+    B, cin, H, W = x.shape
+    pt, pl, pb, pr = (int(p) for p in padding)
+    Ho, Wo = (H + pt + pb - ksize) // stride + 1, (W + pl + pr - ksize) // stride + 1
+    hi = torch.empty((B, cin, H, W), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    lo = torch.empty_like(hi)
+    check(lib().xm3d_split_f16_nhwc(_ptr(x), B, H * W, cin, None, None, None, None, 0, 0.0, 0, 0, F16_X_SCALE, _ptr(hi), _ptr(lo), None, _stream()),
+          "xm3d_split_f16_nhwc")
+    out = torch.empty((B, Ho, Wo, n32), dtype=torch.float32, device=x.device)
+    ldr = 0
+    if residual is not None:
+        if n32 != cout or residual.dtype != torch.float32 or tuple(residual.shape) != (B, cout, Ho, Wo) or not is_nhwc(residual):
+            raise TypeError("conv_gemm_f32: residual must be a channels-last f32 tensor of the output's shape")
+        ldr = n32
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != n32):
+        raise TypeError("conv_gemm_f32: bias must be a contiguous f32 (padded cout,) tensor")
+    m, k = B * Ho * Wo, ksize * ksize * cin
+
+    def run(xt, wp, b, a, alpha, accin, res, ldr_):
+        check(lib().xm3d_gemm_f32acc(_ptr(xt), m, k, 0, _ptr(wp), n32, tile, b, a, alpha, accin, res, ldr_, _ptr(out), n32, 0, 1, B, H, W, cin, ksize, stride,
+                                     pt, pl, Ho, Wo, _stream()), "xm3d_gemm_f32acc")
+
+    _f32acc_passes(run, (hi, lo), packs, out, bias, None, residual, ldr)
     img = out.permute(0, 3, 1, 2)
     return img if n32 == cout else img[:, :cout].contiguous(memory_format=torch.channels_last)
 

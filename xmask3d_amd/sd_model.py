@@ -65,14 +65,35 @@ def _packed_cg(conv):
     return c[1:]
 
 
+def _packed_cg32(conv):
+    """([packed hi, packed lo], column tile, padded cout, padded f32 bias or None) of a frozen f32 Conv2d for ops.conv_gemm_f32"""
+    w = conv.weight
+    key = (w.data_ptr(), w._version, w.dtype)
+    c = conv.__dict__.get("_xm3d_cg32")
+    if c is None or c[0] != key:
+        packs, tile, n32 = ops.gemm_pack_weight_f16(w)
+        bias = None
+        if conv.bias is not None:
+            bias = torch.zeros(n32, dtype=torch.float32, device=w.device)
+            bias[:conv.out_channels] = conv.bias.detach().float()
+        c = conv.__dict__["_xm3d_cg32"] = (key, packs, tile, n32, bias)
+    return c[1:]
+
+
 def own_conv(conv, x, with_bias=True, residual=None, padding=None):
     """Conv2d on the implicit-GEMM kernel (csrc/gemm.hip GF_CONV, ops.conv_gemm) - the convolutions the halo-tile kernel does not
     take: strided Downsample, the 16^2 / 8^2 UNet levels, 1x1 - or None when the call is not channels-last bf16 inference on a shape
     the kernel takes (the caller then uses torch).  padding: (top, left, bottom, right) overriding the module's symmetric padding
     (the VAE Downsample pads bottom / right only).  Unlike the library's split-K convolutions these are bit-reproducible."""
-    if _CONV_GEMM_LIBRARY or torch.is_grad_enabled() or not fused_nhwc(x) or conv.weight.dtype != torch.bfloat16:
+    if _CONV_GEMM_LIBRARY or torch.is_grad_enabled() or not fused_nhwc(x):
         return None
-    if x.dtype != torch.bfloat16:
+    f32 = x.dtype == torch.float32 and conv.weight.dtype == torch.float32
+    if f32:
+        if not gemm_f32_on():
+            return None
+    elif conv.weight.dtype != torch.bfloat16:
+        return None
+    elif x.dtype != torch.bfloat16:
         # f32 activations into a bf16-weight convolution only happen under bf16 autocast (the trainable heads' inference): autocast
         # itself would round x to bf16 here - do the same, one pass, and stay on the own kernel
         if not (x.dtype == torch.float32 and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16):
@@ -82,10 +103,15 @@ def own_conv(conv, x, with_bias=True, residual=None, padding=None):
     if not (k[0] == k[1] and k[0] <= 3 and conv.stride[0] == conv.stride[1] and conv.dilation == (1, 1) and conv.groups == 1
             and isinstance(conv.padding, tuple) and conv.in_channels % 64 == 0 and x.shape[1] == conv.in_channels):
         return None
+    pad = padding if padding is not None else (conv.padding[0], conv.padding[1], conv.padding[0], conv.padding[1])
+    if f32:  # fp32 configuration: the same kernel to f32 accuracy (three passes over operands split in halves)
+        packs, tile, n32, bias = _packed_cg32(conv)
+        if residual is not None and n32 != conv.out_channels:
+            return None
+        return ops.conv_gemm_f32(x, packs, tile, n32, conv.out_channels, k[0], conv.stride[0], pad, bias=bias if with_bias else None, residual=residual)
     packed, tile, n32, bias = _packed_cg(conv)
     if residual is not None and n32 != conv.out_channels:
         return None
-    pad = padding if padding is not None else (conv.padding[0], conv.padding[1], conv.padding[0], conv.padding[1])
     return ops.conv_gemm(x, packed, tile, n32, conv.out_channels, k[0], conv.stride[0], pad, bias=bias if with_bias else None, residual=residual)
 
 
@@ -125,17 +151,15 @@ def conv_nobias(conv: nn.Conv2d, x):
 # ---- fused GroupNorm -> SiLU -> conv3x3 (csrc/conv.hip, xm3d_conv3x3_nhwc): the ResnetBlock halves of both frozen nets
 def fused_conv_ok(x, conv, upsample=False):
     """channels-last inference on a shape the HIP convolution takes: bf16 (xm3d_conv3x3_nhwc; XM3D_CONV=library switches it off for A/B
-    runs) or f32 through the split-operand form (ops.conv3x3_f32, the fp32 configuration): by default three bf16 terms per operand
-    and six matrix-core passes, ~1e-6 per layer - the rounding level of an f32 convolution, per-stage parity of the fp32 forward
-    unchanged against the library's f32 convolutions.  XM3D_CONV_F32=hip selects the two-term / three-pass form (2e-5 per layer;
-    fp32 configuration 1.35 x faster, but per-point logits 6e-4 instead of 1.5e-4 against the oracle - north_star: 1e-3 - so it stays
-    an opt-in), XM3D_CONV_F32=library the torch convolutions (conv_f32_terms)."""
+    runs) or f32 through the split-operand form (ops.conv3x3_f32, the fp32 configuration): by default two terms in IEEE halves per
+    operand and three matrix-core passes, ~1e-6 per layer - the rounding level of an f32 convolution, per-stage parity of the fp32
+    forward unchanged against the library's f32 convolutions (conv_f32_terms: the other forms, A/B switches)."""
     if not (fused_nhwc(x) and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
             and conv.groups == 1 and x.shape[1] == conv.in_channels and os.environ.get("XM3D_CONV", "hip") != "library"):
         return False
     if x.dtype == torch.bfloat16:
         return ops.conv3x3_supported(x, conv.out_channels, upsample)
-    return (x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and conv_f32_terms() > 0
+    return (x.dtype == torch.float32 and conv.weight.dtype == torch.float32 and conv_f32_terms() != 0
             and ops.conv3x3_f32_supported(x, conv.out_channels, upsample))
 
 
@@ -151,15 +175,16 @@ def _packed(conv):
 
 
 def conv_f32_terms():
-    """XM3D_CONV_F32: "hip3" (default: three-term split, six bf16 MFMA passes, ~1e-6 per layer - the rounding level of an f32
-    convolution), "hip" (two-term split, three passes, 2e-5 per layer: opt-in, see fused_conv_ok), "library" (torch / MIOpen f32)"""
-    return {"hip": 2, "hip2": 2, "hip3": 3}.get(os.environ.get("XM3D_CONV_F32", "hip3"), 0)
+    """XM3D_CONV_F32: "f16" (default: the two-term split in IEEE halves, three matrix-core passes, ~1e-6 per layer - the rounding level of
+    an f32 convolution), "hip3" (three bf16 terms, six passes, the same accuracy: round 3's default), "hip" (two bf16 terms, three passes,
+    2e-5 per layer: A/B only), "library" (torch / MIOpen f32).  -> "f16" | 3 | 2 | 0"""
+    return {"f16": "f16", "hip": 2, "hip2": 2, "hip3": 3}.get(os.environ.get("XM3D_CONV_F32", "f16"), 0)
 
 
 def _packed_split(conv):
     """(packed weight terms, cout tile, f32 bias) of a frozen f32 Conv2d: the bf16 split of its weight, built once per weight storage"""
     w = conv.weight
-    terms = conv_f32_terms() or 3
+    terms = conv_f32_terms() or "f16"
     key = (w.data_ptr(), w._version, w.dtype, terms)
     c = conv.__dict__.get("_xm3d_pack_split")
     if c is None or c[0] != key:
@@ -215,14 +240,25 @@ def gemm_ok(x, n_rows, act=None, fused_residual=False):
     attention's context projections (K <= 768), plus the feed-forward output projections of the 64^2 / 32^2 levels, where the residual
     add rides in the epilogue (x1.03 - 1.11).  The MFMA-bound ones (the 16^2 level, the 640 / 1280-wide GEGLU, mask-CLIP) stay on
     hipBLASLt, which is 1.0 - 1.3 x faster there."""
-    if _GEMM_LIBRARY or torch.is_grad_enabled() or not x.is_cuda or x.dtype != torch.bfloat16:
+    if _GEMM_LIBRARY or torch.is_grad_enabled() or not x.is_cuda:
         return False
     k = x.shape[-1]
+    if x.dtype == torch.float32:
+        # fp32 configuration: every projection on the f32-accurate GEMM (three matrix-core passes over operands split in halves,
+        # ops.gemm_f32): 1.3 - 2 x the library's f32 GEMM, and bit-reproducible
+        return gemm_f32_on() and x.dim() >= 2 and k % 64 == 0 and n_rows % 32 == 0 and x.numel() > 0
+    if x.dtype != torch.bfloat16:
+        return False
     if act == "geglu":
         wins = k <= 320
     else:
         wins = k <= 768 or (fused_residual and k <= 2560 and n_rows <= 640)
     return wins and ops.gemm_supported(x, n_rows, k)
+
+
+def gemm_f32_on():
+    """XM3D_GEMM_F32=library: the fp32 configuration's GEMMs / non-3x3 convolutions back on torch (hipBLASLt / MIOpen f32), for A/B runs"""
+    return os.environ.get("XM3D_GEMM_F32", "hip") != "library"
 
 
 def _packed_lin(mods, act=None):
@@ -243,11 +279,71 @@ def _packed_lin(mods, act=None):
     return c[1:]
 
 
+def _packed_lin_f32(mods):
+    """([packed hi, packed lo], column tile, f32 bias or None, rows) of frozen f32 Linear / 1x1 Conv2d weights (stacked) for ops.gemm_f32"""
+    mods = list(mods) if isinstance(mods, (list, tuple)) else [mods]
+    key = tuple((m.weight.data_ptr(), m.weight._version, m.weight.dtype) for m in mods)
+    cache = mods[0].__dict__.setdefault("_xm3d_gemm", {})
+    c = cache.get((len(mods), "f16split"))
+    if c is None or c[0] != key:
+        w = torch.cat([m.weight.detach().reshape(m.weight.shape[0], -1) for m in mods], 0)
+        packs, tile, n32 = ops.gemm_pack_weight_f16(w)
+        assert n32 == w.shape[0]
+        bias = None
+        if any(m.bias is not None for m in mods):
+            bias = torch.cat([m.bias.detach().float() if m.bias is not None else torch.zeros(m.weight.shape[0], device=w.device)
+                              for m in mods]).contiguous()
+        c = cache[(len(mods), "f16split")] = (key, packs, tile, bias, w.shape[0])
+    return c[1:]
+
+
 def lin(mods, x, act=None, residual=None, with_bias=True):
     """act(x @ W^T + b) (+ residual) over the last dimension in one launch; mods: a Linear / 1x1 Conv2d or a list of them (stacked).
-    with_bias False: the product alone (the caller folds the bias into a later epilogue)"""
+    with_bias False: the product alone (the caller folds the bias into a later epilogue).  f32 rows: the f32-accurate GEMM."""
+    if x.dtype == torch.float32:
+        packs, tile, bias, n = _packed_lin_f32(mods)
+        if act == "geglu":
+            return ops.geglu(ops.gemm_f32(x, packs, n, tile, bias=bias if with_bias else None)) if residual is None else \
+                ops.geglu(ops.gemm_f32(x, packs, n, tile, bias=bias if with_bias else None)) + residual
+        if residual is not None and not residual.is_contiguous():
+            residual = residual.contiguous()
+        return ops.gemm_f32(x, packs, n, tile, bias=bias if with_bias else None, act=act, residual=residual)
     packed, tile, bias, n = _packed_lin(mods, act)
     return ops.gemm(x, packed, n, tile, bias=bias if with_bias else None, act=act, residual=residual)
+
+
+_FLIN = {}
+
+
+def flinear(x, weight, bias=None, act=None, residual=None):
+    """F.linear(x, weight, bias) -> act -> + residual on the own GEMM kernels where gemm_ok() says so (GPU inference: bf16 rows on k_gemm
+    where it wins, f32 rows on the f32-accurate GEMM), else torch.  For call sites that hold weight tensors rather than modules
+    (nn.MultiheadAttention's packed in_proj, slices of it); packed images are cached per (storage, shape, version)."""
+    n = weight.shape[0]
+    if gemm_ok(x, n, act, residual is not None) and weight.dtype == x.dtype and weight.is_contiguous():
+        key = (weight.data_ptr(), tuple(weight.shape), weight._version, weight.dtype, bias.data_ptr() if bias is not None else 0)
+        c = _FLIN.get(key)
+        if c is None:
+            b32 = None if bias is None else bias.detach().float().contiguous()
+            if weight.dtype == torch.float32:
+                packs, tile, n32 = ops.gemm_pack_weight_f16(weight)
+                c = (weight, packs, tile, b32) if n32 == n else None
+            else:
+                packed, tile = ops.gemm_pack_weight(weight.detach(), act)
+                c = (weight, packed, tile, b32)
+            _FLIN[key] = c
+        if c is not None:
+            if x.dtype == torch.float32:
+                if residual is not None and not residual.is_contiguous():
+                    residual = residual.contiguous()
+                return ops.gemm_f32(x, c[1], n, c[2], bias=c[3], act=act, residual=residual)
+            return ops.gemm(x, c[1], n, c[2], bias=c[3], act=act, residual=residual)
+    y = F.linear(x, weight, bias)
+    if act == "quick_gelu":
+        y = y * torch.sigmoid(1.702 * y)
+    elif act == "gelu":
+        y = F.gelu(y)
+    return y if residual is None else y + residual
 
 
 def conv1x1_nobias(conv, x):
@@ -364,7 +460,14 @@ class VaeAttnBlock(nn.Module):
     def forward(self, x):
         h = gn_act(self.norm, x)
         b, c, hh, ww = h.shape
-        if fused_nhwc(h) and gemm_ok(tokens_of(h), 3 * c) and (hh * ww) % 4 == 0 and hh * ww <= 8192 \
+        if fused_nhwc(h) and h.dtype == torch.float32 and gemm_ok(tokens_of(h), 3 * c):
+            # fp32 configuration: q, k, v from one f32-accurate token GEMM, softmax attention through torch (MATH), proj_out + bias + skip
+            # in the epilogue of another
+            qkv = lin([self.q, self.k, self.v], tokens_of(h))
+            q, k, v = (qkv[..., i * c:(i + 1) * c].unsqueeze(1) for i in range(3))
+            o = F.scaled_dot_product_attention(q, k, v)[:, 0]
+            return image_of(lin(self.proj_out, o, residual=tokens_of(x)), hh, ww)
+        if fused_nhwc(h) and h.dtype == torch.bfloat16 and gemm_ok(tokens_of(h), 3 * c) and (hh * ww) % 4 == 0 and hh * ww <= 8192 \
                 and os.environ.get("XM3D_GEMM_1X1", "hip") != "library":
             # channels-last: q, k, v from ONE token GEMM (k_gemm), scores / softmax / product as below, proj_out + bias + skip in the
             # epilogue of another - no transposes, no separate bias / residual pass
@@ -603,6 +706,9 @@ class CrossAttention(nn.Module):
                 k, v = (kv[..., i * inner:(i + 1) * inner].unflatten(-1, (h, -1)) for i in range(2))
             if ops.attention_supported(q, k, v):
                 return lin(self.to_out[0], ops.attention(q, k, v).view(b, n, -1))
+            if x.dtype == torch.float32:  # fp32 configuration: f32-accurate projections around torch's MATH attention
+                o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).reshape(b, n, -1)
+                return lin(self.to_out[0], o)
         q = self.to_q(x).view(b, n, h, -1)
         k = self.to_k(context).view(b, context.shape[1], h, -1)
         v = self.to_v(context).view(b, context.shape[1], h, -1)
