@@ -135,6 +135,16 @@ int xm3d_spconv_fwd_split2(const float* in, const void* in_split, int64_t n_in, 
                            int32_t cout, const int32_t* tsrc, const uint8_t* tdst, const int32_t* tcnt, const int32_t* order,
                            int64_t n_out, const float* scale, const float* shift, const float* residual, int32_t relu,
                            float* out, void* out_split, int32_t ksplit, float* slab, void* stream);
+/* The plain-bf16 form of the same kernel - the sparse convolution of the bf16 configuration (BASELINE config 2 names bf16): activations
+ * are ONE bf16 plane (n, C) in and out (residual too), a product is one MFMA on bf16(W) (the hi plane of the image
+ * xm3d_spconv_pack_weight_split wrote), f32 accumulation, the same tiled rulebook and order of additions (bit-reproducible):
+ *     out = bf16( relu( scale * sum_k in[nbr[k]] @ bf16(W[k]) + shift + residual ) )
+ * A third of the matrix work and half the gathered / written bytes of xm3d_spconv_fwd_split2; accuracy ~1e-2 at the end of
+ * MinkUNet34C (bf16 operands and activations) - the level of the bf16 dense branch, not north_star's 1e-3 (that is the split form).
+ * Replaces ME.MinkowskiConvolution(+Transpose) + BN / ReLU / residual tail like the calls above (mink_unet.py:118-178). */
+int xm3d_spconv_fwd_bf16(const void* in, int64_t n_in, int32_t cin, const void* Wq, int32_t K, int32_t cout, const int32_t* tsrc,
+                         const uint8_t* tdst, const int32_t* tcnt, const int32_t* order, int64_t n_out, const float* scale, const float* shift,
+                         const void* residual, int32_t relu, void* out, int32_t ksplit, float* slab, void* stream);
 int xm3d_spconv_pack_weight_split(const float* W, int32_t K, int32_t cin, int32_t cout, void* Wq, void* stream);
 int xm3d_spconv_split_channels(int32_t cout);
 int xm3d_spconv_fwd_split(const float* in, int64_t n_in, int32_t cin, const void* Wq, int32_t K, int32_t cout,

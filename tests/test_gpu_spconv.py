@@ -81,6 +81,78 @@ def test_split_kernel_every_instantiation(dev, cin, cout):
             assert torch.equal(out, again)
 
 
+@pytest.mark.parametrize("cin,cout", [(32, 32), (64, 32), (32, 64), (64, 64), (96, 96), (128, 96), (96, 256), (192, 128), (256, 256),
+                                      (384, 256), (96, 64)])
+def test_bf16_form_every_instantiation(dev, cin, cout):
+    """the plain-bf16 form (xm3d_spconv_fwd_bf16: one bf16 plane in / out, one MFMA per product - the bf16 configuration's sparse
+    convolution): every instantiation, k = 3 / 1, with and without split-K.  Against the f64 oracle evaluated on the SAME bf16-rounded
+    operands (features, weights, residual) the only differences are the f32 summation order and the bf16 rounding of the result:
+    bound 2^-8 relative to max|out| (measured <= 2e-3); an integer-valued case must be exact; bitwise reproducible."""
+    from xmask3d_amd import ops
+
+    torch.manual_seed(cin * 5 + cout)
+    c = _coords(2300, cin + cout + 1, hi=20)
+    N = len(c)
+    cm = ops.CoordinateManager(torch.from_numpy(c).to(dev))
+    bf = lambda t: t.to(torch.bfloat16)
+    f = bf(torch.randn(N, cin))
+    scale, shift, res = torch.rand(cout) + 0.5, torch.randn(cout), bf(torch.randn(N, cout))
+    for ks in (3, 1):
+        nbr = None if ks == 1 else cm.kernel_map(1, 1, ks)
+        tiles = cm.tiles(1, 1, ks)
+        W = torch.randn(ks ** 3, cin, cout) / (cin * 4) ** 0.5
+        packed = ops.pack_weight_split(W.to(dev))
+        ident = torch.arange(N, dtype=torch.int32)[None].numpy()
+        ref = so.spconv(f.double(), bf(W).double(), ident if nbr is None else nbr.cpu().numpy()).float()
+        ref_epi = torch.relu(ref * scale + shift + res.float())
+        for ksplit in (1, 3 if ks == 3 else 1):
+            out = ops.spconv_fwd_bf16(f.to(dev), tuple(W.shape), packed, tiles, N, order=cm.order(1), ksplit=ksplit)
+            assert out.dtype == torch.bfloat16 and _rel(out.float().cpu(), ref) < 4e-3, (ks, ksplit, _rel(out.float().cpu(), ref))
+            out2 = ops.spconv_fwd_bf16(f.to(dev), tuple(W.shape), packed, tiles, N, order=cm.order(1), scale=scale.to(dev), shift=shift.to(dev),
+                                       residual=res.to(dev), relu=True, ksplit=ksplit)
+            assert _rel(out2.float().cpu(), ref_epi) < 4e-3
+            again = ops.spconv_fwd_bf16(f.to(dev), tuple(W.shape), packed, tiles, N, order=cm.order(1), ksplit=ksplit)
+            assert torch.equal(out, again)
+    # exact on small integers: features in {-2..2}, sparse {-1, 0, 1} weights - every product and sum representable in bf16 / f32
+    g = torch.Generator().manual_seed(1)
+    fi = torch.randint(-2, 3, (N, cin), generator=g).float()
+    Wi = (torch.randint(-1, 2, (27, cin, cout), generator=g) * (torch.rand(27, cin, cout, generator=g) < 4.0 / cin)).float()
+    nbr, tiles = cm.kernel_map(1, 1, 3), cm.tiles(1, 1, 3)
+    refi = so.spconv(fi.double(), Wi.double(), nbr.cpu().numpy()).float()
+    assert float(refi.abs().max()) <= 256
+    outi = ops.spconv_fwd_bf16(bf(fi).to(dev), tuple(Wi.shape), ops.pack_weight_split(Wi.to(dev)), tiles, N, order=cm.order(1))
+    assert torch.equal(outi.float().cpu(), refi)
+
+
+def test_bf16_sparse_nets_track_the_f32_nets(dev):
+    """MinkUNet34C + heads and MinkUNet18A + head in the bf16 configuration's sparse mode (XMASK3d.set_sparse_dtype(bf16): bf16
+    activations between the layers, plain-bf16 convolutions) against the same nets in f32 (split-operand kernels, ~f32 accuracy): the
+    budget of the bf16 sparse branch, measured 1e-2 (34C features) / 4e-3 (18A logits) on S1-like clouds - the level of the bf16 dense
+    branch it conditions, not north_star's 1e-3 (the fp32 configuration keeps the f32 form)."""
+    from xmask3d_amd import me_compat as ME
+    from xmask3d_amd.pc_processor import PC_Binary_Processor, PC_Processor
+
+    torch.manual_seed(11)
+    c = _coords(9000, 3, hi=48, batches=2)
+    coords = torch.from_numpy(c).to(dev)
+    feats = (torch.rand(len(c), 3) * 2 - 1).to(dev)
+    for net in (PC_Processor().to(dev).eval(), PC_Binary_Processor().to(dev).eval()):
+        with torch.no_grad():
+            ref = net(ME.SparseTensor(feats, coords))
+            for m in net.modules():
+                if isinstance(m, ME._ConvBase):
+                    m.bf16_io = True
+            got = net(ME.SparseTensor(feats, coords))
+            got2 = net(ME.SparseTensor(feats, coords))
+        ref, got, got2 = (r if isinstance(r, tuple) else (r,) for r in (ref, got, got2))
+        for a, b, b2 in zip(ref, got, got2):
+            if a.dtype.is_floating_point:
+                assert b.dtype == torch.float32 and torch.equal(b, b2)
+                assert _rel(b, a) < 4e-2, _rel(b, a)
+            else:
+                assert torch.equal(a, b)
+
+
 def test_presplit_activations_chain(dev):
     """algo 4 with activations kept pre-split between layers: conv1 emits the bf16 hi / lo copy of its output, conv2 consumes
     it (producers then only move fragments); same result as the on-the-fly split, the copy reconstructs the f32 output to

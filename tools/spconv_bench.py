@@ -49,9 +49,11 @@ for ts_in, ts_out, ks, tr, cin, cout in layers:
     fs = torch.stack([feats.bfloat16(), (feats - feats.bfloat16().float()).bfloat16()]).contiguous()
     t5 = timeit(lambda: ops.spconv_fwd(feats, W, nbr, n_out, order=order, packed=p4, tiles=tiles, relu=True, algo=ops.ALGO_SPLIT,
                                        feats_split=fs, want_split=True))
+    fb = feats.bfloat16().contiguous()
+    t6 = timeit(lambda: ops.spconv_fwd_bf16(fb, tuple(W.shape), p4, tiles, n_out, order=order, relu=True))
     o3 = ops.spconv_fwd(feats, W, nbr, n_out, order=order, packed=p3, tiles=tiles, relu=True, algo=ops.ALGO_TILES)
     o4 = ops.spconv_fwd(feats, W, nbr, n_out, order=order, packed=p4, tiles=tiles, relu=True, algo=ops.ALGO_SPLIT)
     err = ((o3 - o4).abs().max() / o3.abs().max()).item()
     flop = 2.0 * pairs * cin * cout
     print(f"ts {ts_in}->{ts_out} k{ks}{'T' if tr else ' '} {cin:3d}->{cout:3d} rows {n_out:6d} pairs {pairs:7d}: f32 {t3:7.1f} us ({flop / t3 / 1e6:6.1f} TF)  "
-          f"split {t4:7.1f} us ({flop / t4 / 1e6:6.1f} TF)  x{t3 / t4:4.2f}  pre-split in+out {t5:7.1f} us ({flop / t5 / 1e6:6.1f} TF)  |f32-split| {err:.1e}", flush=True)
+          f"split {t4:7.1f} us ({flop / t4 / 1e6:6.1f} TF)  x{t3 / t4:4.2f}  pre-split in+out {t5:7.1f} us ({flop / t5 / 1e6:6.1f} TF)  bf16 form {t6:7.1f} us ({flop / t6 / 1e6:6.1f} TF)  |f32-split| {err:.1e}", flush=True)

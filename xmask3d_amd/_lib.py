@@ -40,6 +40,7 @@ _SIGS = {
     "xm3d_spconv_fwd_tiles": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "xm3d_spconv_fwd_split": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "xm3d_spconv_fwd_split2": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_vp, c_i32, c_vp, c_vp]),
+    "xm3d_spconv_fwd_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, c_vp, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp, c_i32, c_vp, c_vp]),
     "xm3d_spconv_pack_weight_split": (ctypes.c_int, [c_vp, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_spconv_split_channels": (ctypes.c_int, [c_i32]),
     "xm3d_spconv_tile_channels": (ctypes.c_int, [c_i32, c_i32]),

@@ -99,7 +99,8 @@ int exclusive_scan_i32(const int32_t* in, int32_t* out, int64_t n, void* ws, siz
 
 // out = epi(sum_z slab[z]) in fixed z order (spconv.hip; shared by the split-K paths of both sparse-conv kernels)
 int launch_slab_reduce(const float* slab, int ksplit, int64_t n_out, int cout, const float* scale, const float* shift,
-                       const float* residual, int relu, float* out, hipStream_t s, void* out_hi = nullptr, void* out_lo = nullptr);
+                       const float* residual, int relu, float* out, hipStream_t s, void* out_hi = nullptr, void* out_lo = nullptr,
+                       const void* residual_bf = nullptr);
 
 // f32 x 4 -> bf16 hi / lo parts (x = hi + lo up to 2^-17 |x|), 8-byte stores: the pre-split activation format of the
 // split-operand sparse conv (spconv_split.hip)

@@ -411,7 +411,7 @@ __global__ __launch_bounds__(256, (NTT <= 2 ? 2 : 1)) void k_spconv_tiles(const 
 __global__ void k_slab_reduce(const float* __restrict__ slab, int ksplit, int64_t n4, int64_t stride4, int c,
                               const float* __restrict__ scale, const float* __restrict__ shift,
                               const float* __restrict__ residual, int relu, float* __restrict__ out,
-                              __bf16* __restrict__ out_hi, __bf16* __restrict__ out_lo) {
+                              __bf16* __restrict__ out_hi, __bf16* __restrict__ out_lo, const __bf16* __restrict__ residual_bf) {
     const int64_t gs = int64_t(gridDim.x) * blockDim.x;
     for (int64_t e = int64_t(blockIdx.x) * blockDim.x + threadIdx.x; e < n4; e += gs) {
         f32x4 v = reinterpret_cast<const f32x4*>(slab)[e];
@@ -420,25 +420,37 @@ __global__ void k_slab_reduce(const float* __restrict__ slab, int ksplit, int64_
         if (scale) v *= *reinterpret_cast<const f32x4*>(scale + ch);
         if (shift) v += *reinterpret_cast<const f32x4*>(shift + ch);
         if (residual) v += reinterpret_cast<const f32x4*>(residual)[e];
+        if (residual_bf) {  // the bf16 form: residual and result are single bf16 planes
+            typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
+            const bf16x4e r = reinterpret_cast<const bf16x4e*>(residual_bf)[e];
+            v[0] += float(r[0]), v[1] += float(r[1]), v[2] += float(r[2]), v[3] += float(r[3]);
+        }
         if (relu) {
             v[0] = fmaxf(v[0], 0.f);
             v[1] = fmaxf(v[1], 0.f);
             v[2] = fmaxf(v[2], 0.f);
             v[3] = fmaxf(v[3], 0.f);
         }
-        reinterpret_cast<f32x4*>(out)[e] = v;
-        if (out_hi) store_split4(out_hi + e * 4, out_lo + e * 4, v);
+        if (out) reinterpret_cast<f32x4*>(out)[e] = v;
+        if (out_hi && out_lo) store_split4(out_hi + e * 4, out_lo + e * 4, v);
+        else if (out_hi) {
+            typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
+            bf16x4e o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (__bf16)v[i];
+            reinterpret_cast<bf16x4e*>(out_hi)[e] = o;
+        }
     }
 }
 
 // host-side launcher shared with spconv_split.hip
 int launch_slab_reduce(const float* slab, int ksplit, int64_t n_out, int cout, const float* scale, const float* shift,
-                       const float* residual, int relu, float* out, hipStream_t s, void* out_hi, void* out_lo) {
+                       const float* residual, int relu, float* out, hipStream_t s, void* out_hi, void* out_lo, const void* residual_bf) {
     const int64_t n4 = n_out * cout / 4;
     int64_t blocks = (n4 + 255) / 256;
     if (blocks > 2048) blocks = 2048;
     hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out,
-                       static_cast<__bf16*>(out_hi), static_cast<__bf16*>(out_lo));
+                       static_cast<__bf16*>(out_hi), static_cast<__bf16*>(out_lo), static_cast<const __bf16*>(residual_bf));
     return 0;
 }
 
@@ -646,7 +658,7 @@ extern "C" int xm3d_spconv_fwd_tiles(const float* in, int64_t n_in, int32_t cin,
             int64_t blocks = (n4 + 255) / 256;
             if (blocks > 2048) blocks = 2048;
             hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out,
-                               static_cast<__bf16*>(nullptr), static_cast<__bf16*>(nullptr));
+                               static_cast<__bf16*>(nullptr), static_cast<__bf16*>(nullptr), static_cast<const __bf16*>(nullptr));
         }
         XM3D_LAUNCH_CHECK();
         return XM3D_OK;
@@ -665,7 +677,7 @@ extern "C" int xm3d_spconv_fwd_tiles(const float* in, int64_t n_in, int32_t cin,
         int64_t blocks = (n4 + 255) / 256;
         if (blocks > 2048) blocks = 2048;
         hipLaunchKernelGGL(k_slab_reduce, dim3(blocks), dim3(256), 0, s, slab, ksplit, n4, n4, cout, scale, shift, residual, relu, out,
-                               static_cast<__bf16*>(nullptr), static_cast<__bf16*>(nullptr));
+                               static_cast<__bf16*>(nullptr), static_cast<__bf16*>(nullptr), static_cast<const __bf16*>(nullptr));
     }
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;

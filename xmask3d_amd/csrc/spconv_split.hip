@@ -77,10 +77,10 @@ __global__ void k_pack_weight_split(const float* __restrict__ W, int K, int cin,
     Wq[base + 512] = lo;
 }
 
-template <int NT, int CC, int IPC>
+template <int NT, int CC, int IPC, int NPL = 2>
 struct __attribute__((aligned(16))) SplitLds {
     float acc[SROWS][16 * NT + 4];        // padded rows: 16-byte aligned, breaks the bank stride
-    uint4 stage[2][IPC][CC / 32][2][64];  // [slot][item][k-step][hi/lo][lane] bf16x8 fragments (B operand)
+    uint4 stage[2][IPC][CC / 32][NPL][64];  // [slot][item][k-step][hi/lo][lane] bf16x8 fragments (B operand); NPL = 1: bf16 form, hi only
     int dst[2][IPC][16];                  // local output row of each pair slot (-1 = padding)
     int nzk[128], nzc[128];               // non-empty offsets of this tile (compacted): offset slot, pair count
     int nnz;
@@ -111,14 +111,18 @@ __device__ __forceinline__ void load_frag(uint4& dst, const uint4* sbase, unsign
 // offset), so the accumulator updates inside a chunk are independent, and its weights are one fragment set.
 // PRE: the input also exists pre-split (in_hi / in_lo bf16 planes, written by the epilogue of the conv that produced it): the
 // producers then only move fragments (two 16-byte loads + two LDS stores per 32-channel step instead of 24 conversion VALU ops).
-template <int NT, int NTW, int CC, int IPC, int NG, int NPW, bool PRE>
+// BF (needs PRE): the plain-bf16 form of the bf16 configuration - activations exist ONLY as one bf16 plane (in_hi / out_hi; residual is a
+// bf16 plane too), a product is ONE MFMA on the hi parts: a third of the matrix work, half the gathered, staged and written bytes.
+template <int NT, int NTW, int CC, int IPC, int NG, int NPW, bool PRE, bool BF = false>
 __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
     const float* __restrict__ in, const __bf16* __restrict__ in_hi, const __bf16* __restrict__ in_lo, __bf16* __restrict__ out_hi,
     __bf16* __restrict__ out_lo, int cin, const uint4* __restrict__ Wq, int K, int cout, const int32_t* __restrict__ tsrc,
     const uint8_t* __restrict__ tdst, const int32_t* __restrict__ tcnt, const int32_t* __restrict__ order, int64_t n_out,
     const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ residual, int relu,
     float* __restrict__ out, int ksplit, float* __restrict__ slab, int ntiles) {
-    __shared__ SplitLds<NT, CC, IPC> lds;
+    static_assert(!BF || PRE, "the bf16 form reads a bf16 plane");
+    constexpr int NPL = BF ? 1 : 2;            // operand planes (hi / lo)
+    __shared__ SplitLds<NT, CC, IPC, NPL> lds;
     constexpr int S = CC / 32;                 // k-steps per item
     constexpr int CTT = 16 * NT, ACCLD = CTT + 4;
     constexpr int NCONS = NT / NTW;
@@ -126,7 +130,7 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
     constexpr int NTHREADS = 64 * (NCONS + NP);
     constexpr int IPP = IPC / NPW;             // items per producer wave per chunk
     constexpr int WD = 3;                      // weight fragment sets per consumer (loaded two chunks ahead)
-    constexpr int WLOADS = NTW * S * 2;        // 1-KiB loads per weight set
+    constexpr int WLOADS = NTW * S * NPL;      // 1-KiB loads per weight set
     static_assert(IPC % NPW == 0 && NT % NTW == 0 && NG >= 2, "IPC must be a multiple of NPW, NT of NTW");
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -208,7 +212,7 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
         const int g = __builtin_amdgcn_readfirstlane(p / NPW), m = __builtin_amdgcn_readfirstlane(p % NPW);
         int a_src[IPP], a_dst[IPP], a_c;
         bool a_ok[IPP];
-        f32x4 rows[IPP][2 * S];
+        f32x4 rows[IPP][NPL * S];
         ChunkIt it_mine = it0;  // my group's next chunk
         for (int i = 0; i < g; ++i) it_mine = next(it_mine);
 
@@ -239,7 +243,9 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
                 const int64_t eo = int64_t(a_ok[u] ? a_src[u] : 0) * cin + a_c * CC + 8 * q;  // this lane's 8 channels per step
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    if constexpr (PRE) {  // ready-made bf16 hi / lo fragments
+                    if constexpr (BF) {  // the one bf16 plane
+                        rows[u][s] = *reinterpret_cast<const f32x4*>(in_hi + eo + 32 * s);
+                    } else if constexpr (PRE) {  // ready-made bf16 hi / lo fragments
                         rows[u][2 * s] = *reinterpret_cast<const f32x4*>(in_hi + eo + 32 * s);
                         rows[u][2 * s + 1] = *reinterpret_cast<const f32x4*>(in_lo + eo + 32 * s);
                     } else {
@@ -255,7 +261,9 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
                 const int e = m * IPP + u;
 #pragma unroll
                 for (int s = 0; s < S; ++s) {
-                    if constexpr (PRE) {
+                    if constexpr (BF) {
+                        lds.stage[slot][e][s][0][lane] = __builtin_bit_cast(uint4, rows[u][s]);
+                    } else if constexpr (PRE) {
                         lds.stage[slot][e][s][0][lane] = __builtin_bit_cast(uint4, rows[u][2 * s]);
                         lds.stage[slot][e][s][1][lane] = __builtin_bit_cast(uint4, rows[u][2 * s + 1]);
                     } else {
@@ -305,7 +313,7 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
         // COUNTED vmcnt that leaves the two younger sets in flight (loads retire in order, these are the wave's only
         // vector-memory operations inside the loop).
         const int ng0 = ct0 / 16 + wave * NTW;
-        uint4 W[WD][NTW][S][2];
+        uint4 W[WD][NTW][S][NPL];
         const unsigned voff = lane * 16;
         auto load_w = [&](auto SETc, ChunkIt t) __attribute__((always_inline)) {
             constexpr int SET = decltype(SETc)::value;
@@ -321,10 +329,10 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
                 const uint32_t ahi = uint32_t(__builtin_amdgcn_readfirstlane(int(uint32_t(a64 >> 32))));
                 const uint4* sb = reinterpret_cast<const uint4*>((uint64_t(ahi) << 32) | uint64_t(alo));
                 load_frag<0>(W[SET][0][s][0], sb, voff);
-                load_frag<1024>(W[SET][0][s][1], sb, voff);
+                if constexpr (!BF) load_frag<1024>(W[SET][0][s][NPL - 1], sb, voff);
                 if constexpr (NTW > 1) {
                     load_frag<2048>(W[SET][NTW > 1 ? 1 : 0][s][0], sb, voff);
-                    load_frag<3072>(W[SET][NTW > 1 ? 1 : 0][s][1], sb, voff);
+                    if constexpr (!BF) load_frag<3072>(W[SET][NTW > 1 ? 1 : 0][s][NPL - 1], sb, voff);
                 }
                 static_assert(NTW <= 2, "immediate offsets cover two 16-channel tiles per consumer");
             }
@@ -362,12 +370,11 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
                     drow[e] = lds.dst[slot][e][p16];
                     if (e >= nitems) drow[e] = -1;
                 }
-                uint4 B[2][S][2];
+                uint4 B[2][S][NPL];
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    B[0][s][0] = lds.stage[slot][0][s][0][lane];
-                    B[0][s][1] = lds.stage[slot][0][s][1][lane];
-                }
+                for (int s = 0; s < S; ++s)
+#pragma unroll
+                    for (int pl = 0; pl < NPL; ++pl) B[0][s][pl] = lds.stage[slot][0][s][pl][lane];
 #pragma unroll
                 for (int e = 0; e < IPC; ++e)
 #pragma unroll
@@ -378,10 +385,9 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
                 for (int e = 0; e < IPC; ++e) {
                     if (e + 1 < IPC) {
 #pragma unroll
-                        for (int s = 0; s < S; ++s) {
-                            B[(e + 1) & 1][s][0] = lds.stage[slot][e + 1][s][0][lane];
-                            B[(e + 1) & 1][s][1] = lds.stage[slot][e + 1][s][1][lane];
-                        }
+                        for (int s = 0; s < S; ++s)
+#pragma unroll
+                            for (int pl = 0; pl < NPL; ++pl) B[(e + 1) & 1][s][pl] = lds.stage[slot][e + 1][s][pl][lane];
                     }
                     if (e < nitems) {
                         f32x4 d[NTW];
@@ -390,13 +396,15 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
 #pragma unroll
                         for (int s = 0; s < S; ++s) {
                             const bf16x8 bhi = __builtin_bit_cast(bf16x8, B[e & 1][s][0]);
-                            const bf16x8 blo = __builtin_bit_cast(bf16x8, B[e & 1][s][1]);
+                            const bf16x8 blo = __builtin_bit_cast(bf16x8, B[e & 1][s][NPL - 1]);
 #pragma unroll
                             for (int t = 0; t < NTW; ++t) {
                                 const bf16x8 ahi = __builtin_bit_cast(bf16x8, W[PH][t][s][0]);
-                                const bf16x8 alo = __builtin_bit_cast(bf16x8, W[PH][t][s][1]);
-                                d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi, d[t], 0, 0, 0);
-                                d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo, d[t], 0, 0, 0);
+                                if constexpr (!BF) {
+                                    const bf16x8 alo = __builtin_bit_cast(bf16x8, W[PH][t][s][NPL - 1]);
+                                    d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(alo, bhi, d[t], 0, 0, 0);
+                                    d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, blo, d[t], 0, 0, 0);
+                                }
                                 d[t] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ahi, bhi, d[t], 0, 0, 0);
                             }
                         }
@@ -429,6 +437,18 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
         }
         if (scale) v *= *reinterpret_cast<const f32x4*>(scale + c);
         if (shift) v += *reinterpret_cast<const f32x4*>(shift + c);
+        if constexpr (BF) {  // the residual is a bf16 plane, the result one bf16 row segment (8 bytes)
+            typedef __bf16 bf16x4e __attribute__((ext_vector_type(4)));
+            if (residual) {
+                const bf16x4e r = *reinterpret_cast<const bf16x4e*>(reinterpret_cast<const __bf16*>(residual) + grow * cout + c);
+                v[0] += float(r[0]), v[1] += float(r[1]), v[2] += float(r[2]), v[3] += float(r[3]);
+            }
+            bf16x4e o;
+#pragma unroll
+            for (int i = 0; i < 4; ++i) o[i] = (__bf16)(relu ? fmaxf(v[i], 0.f) : v[i]);
+            *reinterpret_cast<bf16x4e*>(out_hi + grow * cout + c) = o;
+            continue;
+        }
         if (residual) v += *reinterpret_cast<const f32x4*>(residual + grow * cout + c);
         if (relu) {
             v[0] = fmaxf(v[0], 0.f);
@@ -553,4 +573,54 @@ extern "C" int xm3d_spconv_fwd_split2(const float* in, const void* in_split, int
                                       float* out, void* out_split, int32_t ksplit, float* slab, void* stream) {
     return spconv_fwd_split_impl(in, in_split, n_in, cin, Wq, K, cout, tsrc, tdst, tcnt, order, n_out, scale, shift, residual, relu, out,
                                  out_split, ksplit, slab, stream);
+}
+
+// ---- the plain-bf16 form (BF): the bf16 configuration's sparse convolution.  Activations are ONE bf16 plane (n, C), the product one
+// MFMA per k-step on bf16(w) (the hi plane of the split weight image), f32 accumulation in LDS as above, bf16 rows out:
+//     out = bf16( relu( scale * sum_k in[nbr[k]] @ bf16(W[k]) + shift + residual ) )
+// a third of the matrix work and half the gathered / staged / written bytes of the split form; same rulebook, same order of the
+// additions (bit-reproducible).  Accuracy: bf16 operands and bf16 activations between the layers, ~1e-2 at the end of MinkUNet34C -
+// the level of the bf16 dense branch it feeds, NOT north_star's 1e-3 (that is the f32 / split form, the fp32 configuration's).
+extern "C" int xm3d_spconv_fwd_bf16(const void* in, int64_t n_in, int32_t cin, const void* Wq, int32_t K, int32_t cout, const int32_t* tsrc,
+                                    const uint8_t* tdst, const int32_t* tcnt, const int32_t* order, int64_t n_out, const float* scale,
+                                    const float* shift, const void* residual, int32_t relu, void* out, int32_t ksplit, float* slab, void* stream) {
+    XM3D_REQUIRE(n_in >= 0 && n_out >= 0 && K >= 1, "spconv_fwd_bf16: bad sizes");
+    XM3D_REQUIRE(cin % 32 == 0 && cout % 32 == 0 && cin >= 32, "spconv_fwd_bf16: cin=%d cout=%d must be multiples of 32", cin, cout);
+    if (n_out == 0) return XM3D_OK;
+    XM3D_REQUIRE(in && Wq && tsrc && tdst && tcnt && out, "spconv_fwd_bf16: null pointer");
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(in) | reinterpret_cast<uintptr_t>(out) | reinterpret_cast<uintptr_t>(Wq) | reinterpret_cast<uintptr_t>(residual) |
+                   reinterpret_cast<uintptr_t>(scale) | reinterpret_cast<uintptr_t>(shift)) & 15) == 0,
+                 "spconv_fwd_bf16: tensors must be 16-byte aligned");
+    XM3D_REQUIRE(ksplit >= 1 && ksplit <= K && (ksplit == 1 || slab), "spconv_fwd_bf16: ksplit=%d needs 1..K and a slab", ksplit);
+    XM3D_REQUIRE(K <= 128, "spconv_fwd_bf16: K=%d > 128", K);
+    hipStream_t s = as_stream(stream);
+    const int ntiles = int((n_out + SROWS - 1) / SROWS);
+    const int ctt = xm3d_spconv_split_channels(cout);
+    const int cc = (cin % 64 == 0) ? 64 : (cin % 96 == 0 ? 96 : 32);
+    dim3 grid(ntiles, cout / ctt, ksplit);
+    const uint4* wq = static_cast<const uint4*>(Wq);
+    const __bf16* in_b = static_cast<const __bf16*>(in);
+    __bf16* o_b = ksplit > 1 ? nullptr : static_cast<__bf16*>(out);
+    const float* res = static_cast<const float*>(residual);  // a bf16 plane (the kernel casts back)
+#define XM3D_BF(NT, NTW, CC, IPC, NG, NPW)                                                                                                   \
+    hipLaunchKernelGGL((k_spconv_split<NT, NTW, CC, IPC, NG, NPW, true, true>), grid, dim3(64 * (NT / NTW + NG * NPW)), 0, s, nullptr, in_b, \
+                       nullptr, o_b, nullptr, cin, wq, K, cout, tsrc, tdst, tcnt, order, n_out, scale, shift, res, relu, nullptr, ksplit, slab,  \
+                       ntiles)
+    if (ctt == 96) {
+        if (cc == 96) XM3D_BF(6, 1, 96, 4, 3, 2);
+        else if (cc == 64) XM3D_BF(6, 1, 64, 4, 3, 2);
+        else XM3D_BF(6, 1, 32, 8, 3, 2);
+    } else if (ctt == 64) {
+        if (cc == 96) XM3D_BF(4, 1, 96, 4, 3, 2);
+        else if (cc == 64) XM3D_BF(4, 1, 64, 8, 3, 2);
+        else XM3D_BF(4, 1, 32, 8, 3, 2);
+    } else {
+        if (cc == 96) XM3D_BF(2, 1, 96, 2, 3, 1);
+        else if (cc == 64) XM3D_BF(2, 1, 64, 4, 3, 1);
+        else XM3D_BF(2, 1, 32, 8, 3, 1);
+    }
+#undef XM3D_BF
+    if (ksplit > 1) launch_slab_reduce(slab, ksplit, n_out, cout, scale, shift, nullptr, relu, nullptr, s, out, nullptr, residual);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
 }

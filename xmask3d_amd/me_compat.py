@@ -143,6 +143,12 @@ class _PendingConv:
 
     def run(self):
         """-> (features, pre-split bf16 copy or None)"""
+        if self.feats.dtype == torch.bfloat16:  # the bf16 configuration: one bf16 plane in and out
+            res = self.residual
+            if res is not None and res.dtype != torch.bfloat16:
+                res = res.to(torch.bfloat16)
+            return ops.spconv_fwd_bf16(self.feats, tuple(self.kernel3.shape), self.packed, self.tiles, self.n_out, order=self.order,
+                                       scale=self.scale, shift=self.shift, residual=res, relu=self.relu), None
         r = ops.spconv_fwd(self.feats, self.kernel3, self.nbr, self.n_out, order=self.order, scale=self.scale, shift=self.shift,
                            residual=self.residual, relu=self.relu, packed=self.packed, tiles=self.tiles,
                            feats_split=self.feats_split, want_split=self.emit_split)
@@ -159,7 +165,17 @@ class _PendingAffine:
         return False
 
     def run(self):
-        return ops.affine_act(self.x, self.scale, self.shift, self.residual, self.relu), None
+        if self.x.dtype == torch.bfloat16:  # bf16 configuration, rare (an affine / add / ReLU with no convolution to fold into): torch ops
+            y = self.x.float()
+            if self.scale is not None:
+                y = y * self.scale
+            if self.shift is not None:
+                y = y + self.shift
+            if self.residual is not None:
+                y = y + self.residual.float()
+            return (torch.relu_(y) if self.relu else y).to(torch.bfloat16), None
+        res = self.residual
+        return ops.affine_act(self.x, self.scale, self.shift, res.float() if res is not None and res.dtype != torch.float32 else res, self.relu), None
 
 
 class SparseTensor:
@@ -179,7 +195,7 @@ class SparseTensor:
         self._Fs = None  # (2, N, C) bf16 hi / lo copy of _F, written by the split-operand conv that produced it (eval path)
         self._pending = _pending
         if features is not None:
-            if features.dtype != torch.float32:
+            if features.dtype not in (torch.float32, torch.bfloat16):  # (bf16: the plain-bf16 sparse path of the bf16 configuration)
                 features = features.float()
             self._F = features.contiguous()
             if self._F.shape[0] != coordinate_manager.num(tensor_stride):
@@ -246,7 +262,10 @@ def cat(*tensors):
     for t in tensors[1:]:
         if t.coordinate_manager is not t0.coordinate_manager or t.tensor_stride != t0.tensor_stride:
             raise RuntimeError("ME.cat needs tensors on the same coordinate map")
-    out = t0._like(torch.cat([t.F for t in tensors], dim=1))
+    fs = [t.F for t in tensors]
+    if len({f.dtype for f in fs}) > 1:
+        fs = [f.float() for f in fs]
+    out = t0._like(torch.cat(fs, dim=1))
     if all(t._Fs is not None for t in tensors):  # keep the pre-split copies: hi and lo planes concatenated channel-wise
         out._Fs = torch.cat([t._Fs for t in tensors], dim=2)
     return out
@@ -285,11 +304,11 @@ class _ConvBase(nn.Module):
     def _kernel3(self):
         return self.kernel if self.kernel.dim() == 3 else self.kernel.unsqueeze(0)
 
-    def _packed_weight(self, k3, cin=None):
+    def _packed_weight(self, k3, cin=None, force_split=False):
         cin = self.in_channels if cin is None else cin
         if not ops.mfma_eligible(cin, self.out_channels):
             return None
-        algo = ops.default_tiled_algo(cin, self.out_channels, self.kernel_volume)
+        algo = ops.ALGO_SPLIT if force_split else ops.default_tiled_algo(cin, self.out_channels, self.kernel_volume)
         key = (k3.data_ptr(), self.kernel._version, k3.device, algo)
         if self._packed_key != key:
             pack = ops.pack_weight_split if algo == ops.ALGO_SPLIT else ops.pack_weight
@@ -321,6 +340,13 @@ class _ConvBase(nn.Module):
             k3 = k3.contiguous()
         n_out = cm.num(ts_out)
         cin = self.in_channels
+        cin_pad = 32 if (cin < 32 and self.out_channels % 32 == 0 and self.kernel_volume > 1) else cin
+        bf16 = (getattr(self, "bf16_io", False) or feats.dtype == torch.bfloat16) and ops.mfma_eligible(cin_pad, self.out_channels) \
+            and self.kernel_volume <= 128
+        if bf16 and feats.dtype != torch.bfloat16:
+            feats = feats.to(torch.bfloat16)   # the net's entry: from here on activations are one bf16 plane
+        elif not bf16 and feats.dtype == torch.bfloat16:
+            feats = feats.float()              # a layer the MFMA kernel does not take: back to f32 for the rest of the net
         if cin < 32 and self.out_channels % 32 == 0 and self.kernel_volume > 1:
             # the 3 -> 32 stem (mink_unet.py conv0p1s1, 5^3 offsets): zero-pad the input channels to one 32-channel MFMA step
             # instead of the scalar kernel - same sums (the padded products are exact zeros)
@@ -330,13 +356,13 @@ class _ConvBase(nn.Module):
                 self._padded, self._padded_key = F.pad(k3, (0, 0, 0, 32 - self.in_channels)).contiguous(), key
             k3 = self._padded
             feats = F.pad(feats, (0, 32 - self.in_channels))
-        packed = self._packed_weight(k3, cin)
+        packed = self._packed_weight(k3, cin, force_split=bf16)
         nbr = tiles = None
         if packed is not None:
             tiles = cm.tiles(ts_in, ts_out, self.kernel_size, self.transposed)
         if not (self.kernel_volume == 1 and self.stride == 1):
             nbr = cm.kernel_map(ts_in, ts_out, self.kernel_size, self.transposed)
-        split = packed is not None and ops.default_tiled_algo(cin, self.out_channels, self.kernel_volume) == ops.ALGO_SPLIT
+        split = not bf16 and packed is not None and ops.default_tiled_algo(cin, self.out_channels, self.kernel_volume) == ops.ALGO_SPLIT
         pend = _PendingConv(feats, k3, packed, nbr, cm.order(ts_out), n_out, tiles, feats_split=x._Fs if split else None,
                             emit_split=split and getattr(self, "emit_split", True))
         if self.bias is not None:
@@ -473,7 +499,8 @@ class MinkowskiLinear(nn.Module):
         self.linear = nn.Linear(in_features, out_features, bias=bias)
 
     def forward(self, x):
-        return x._like(self.linear(x.F))
+        f = x.F
+        return x._like(self.linear(f.float() if f.dtype != self.linear.weight.dtype else f))
 
 
 class _NotOnPath(nn.Module):

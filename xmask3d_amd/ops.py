@@ -308,6 +308,28 @@ def spconv_fwd(feats, kernel, nbr, n_out, order=None, scale=None, shift=None, re
     return (out, None) if want_split else out
 
 
+def spconv_fwd_bf16(feats, kernel_shape, packed, tiles, n_out, order=None, scale=None, shift=None, residual=None, relu=False, ksplit=None):
+    """The plain-bf16 form of the split kernel (xm3d_spconv_fwd_bf16): feats (n_in, Cin) bf16 -> (n_out, Cout) bf16; residual bf16 like the
+    output; packed = pack_weight_split(kernel) (its hi plane is used); kernel_shape = (K, Cin, Cout)."""
+    _req(feats, torch.bfloat16, "features", 2)
+    K, cin, cout = kernel_shape
+    if feats.shape[1] != cin or not feats.is_contiguous():
+        raise RuntimeError(f"spconv_fwd_bf16: contiguous (n, {cin}) features required")
+    if residual is not None:
+        _req(residual, torch.bfloat16, "residual", 2)
+        assert tuple(residual.shape) == (n_out, cout) and residual.is_contiguous()
+    tsrc, tdst, tcnt = tiles
+    if ksplit is None:
+        wgs = ((n_out + 255) // 256) * (cout // lib().xm3d_spconv_split_channels(cout))
+        ksplit = 1 if wgs >= 256 else max(1, min(K, -(-_SPLIT_WG_TARGET // max(wgs, 1))))
+    slab = torch.empty((ksplit, n_out, cout), dtype=torch.float32, device=feats.device) if ksplit > 1 else None
+    out = torch.empty((n_out, cout), dtype=torch.bfloat16, device=feats.device)
+    check(lib().xm3d_spconv_fwd_bf16(_ptr(feats), feats.shape[0], cin, _ptr(packed), K, cout, _ptr(tsrc), _ptr(tdst), _ptr(tcnt), _ptr(order), n_out,
+                                     _ptr(scale), _ptr(shift), _ptr(residual), int(bool(relu)), _ptr(out), ksplit, _ptr(slab), _stream()),
+          "xm3d_spconv_fwd_bf16")
+    return out
+
+
 def spconv_bwd_weight(feats, gout, nbr, K):
     """gW (K,Cin,Cout) = sum_o feats[nbr[k,o]]^T gout[o]  (nbr None = K=1 identity map)"""
     _req(feats, torch.float32, "features", 2)

@@ -7,6 +7,21 @@ import torch.nn as nn
 from .mink_unet import mink_unet
 
 
+def _head_linear(lin, x):
+    """nn.Linear of a 3D head on the net's features.  bf16 features (the bf16 configuration's sparse branch, inference): the product in
+    bf16 on a bf16 copy of the trainable weight (k_gemm where it wins), f32 rows out; else the module itself on f32 rows."""
+    if x.dtype == torch.bfloat16 and not torch.is_grad_enabled() and x.is_cuda:
+        from .sd_model import flinear
+
+        key = (lin.weight.data_ptr(), lin.weight._version)
+        c = lin.__dict__.get("_xm3d_bf16")
+        if c is None or c[0] != key:
+            c = lin.__dict__["_xm3d_bf16"] = (key, lin.weight.detach().to(torch.bfloat16).contiguous(),
+                                              None if lin.bias is None else lin.bias.detach().to(torch.bfloat16).contiguous())
+        return flinear(x, c[1], c[2]).float()
+    return lin(x if x.dtype == lin.weight.dtype else x.float())
+
+
 class PC_Processor(nn.Module):
     """MinkUNet34C -> (implicit caption rows (N16,768), per-voxel features (N1,768), batch ids (N16,))."""
 
@@ -20,7 +35,7 @@ class PC_Processor(nn.Module):
     def forward(self, x):
         high_x, out_x = self.encoder(x)
         idx = high_x.C[:, 0]
-        return self.point2text_adapter(high_x.F), self.decoder(out_x.F), idx
+        return _head_linear(self.point2text_adapter, high_x.F), _head_linear(self.decoder, out_x.F), idx
 
 
 class PC_Binary_Processor(nn.Module):
@@ -35,4 +50,4 @@ class PC_Binary_Processor(nn.Module):
 
     def forward(self, x):
         _, out_x = self.encoder(x)
-        return self.fc(self.relu(self.batch_norm(out_x.F)))
+        return self.fc(self.relu(self.batch_norm(out_x.F.float())))

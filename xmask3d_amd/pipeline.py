@@ -45,6 +45,8 @@ def make_inference_model(cpu_model, device, dense_dtype=torch.bfloat16, channels
         model.set_channels_last(True)
     if dense_dtype == torch.bfloat16:
         model.cast_head_weights()
+        if os.environ.get("XM3D_SPARSE", "bf16") != "f32":  # A/B switch: keep the f32-accurate (split-operand) sparse branch under the bf16 nets
+            model.set_sparse_dtype(torch.bfloat16)
     if graphs:
         model.enable_dense_graph()
     return model

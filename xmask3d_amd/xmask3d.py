@@ -128,6 +128,20 @@ class XMASK3d(nn.Module):
         self.criterion.clip.clip.visual.to(dense_dtype)
         return self
 
+    def set_sparse_dtype(self, dtype):
+        """bf16: the two sparse U-Nets run the plain-bf16 form of the sparse convolution at inference (activations one bf16 plane, one
+        MFMA per product: csrc/spconv_split.hip BF) - the bf16 configuration; f32 (default): f32 activations, split-operand products
+        (~f32 accuracy: the fp32 configuration and training)."""
+        from . import me_compat
+
+        on = dtype == torch.bfloat16
+        for net in (self.pc_decoder, self.pc_binary_head):
+            for m in net.modules():
+                if isinstance(m, me_compat._ConvBase):
+                    m.bf16_io = on
+        self.sparse_dtype = dtype
+        return self
+
     def cast_head_weights(self, dtype=torch.bfloat16):
         """Inference only: hold the GEMM / convolution weights of the trainable heads that run under bf16 autocast (feature
         projections, pixel decoder, transformer decoder) in bf16, so that autocast finds nothing to cast - otherwise every
