@@ -113,7 +113,10 @@ __device__ __forceinline__ void load_frag(uint4& dst, const uint4* sbase, unsign
 // producers then only move fragments (two 16-byte loads + two LDS stores per 32-channel step instead of 24 conversion VALU ops).
 // BF (needs PRE): the plain-bf16 form of the bf16 configuration - activations exist ONLY as one bf16 plane (in_hi / out_hi; residual is a
 // bf16 plane too), a product is ONE MFMA on the hi parts: a third of the matrix work, half the gathered, staged and written bytes.
-template <int NT, int NTW, int CC, int IPC, int NG, int NPW, bool PRE, bool BF = false>
+// G: chunks per barrier interval.  A chunk stays "up to IPC items of ONE offset" (one weight set, distinct output rows), but the ring slot
+// holds G of them and the workgroup barrier comes once per G chunks: at the rulebook densities of the path an offset has 2 - 3 items per
+// 256-row tile, so with one chunk per interval a tile was ~27 latency-bound intervals of ~3 k cycles with ~430 cycles of matrix work each.
+template <int NT, int NTW, int CC, int IPC, int NG, int NPW, bool PRE, bool BF = false, int G = 1>
 __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
     const float* __restrict__ in, const __bf16* __restrict__ in_hi, const __bf16* __restrict__ in_lo, __bf16* __restrict__ out_hi,
     __bf16* __restrict__ out_lo, int cin, const uint4* __restrict__ Wq, int K, int cout, const int32_t* __restrict__ tsrc,
@@ -122,7 +125,7 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
     float* __restrict__ out, int ksplit, float* __restrict__ slab, int ntiles) {
     static_assert(!BF || PRE, "the bf16 form reads a bf16 plane");
     constexpr int NPL = BF ? 1 : 2;            // operand planes (hi / lo)
-    __shared__ SplitLds<NT, CC, IPC, NPL> lds;
+    __shared__ SplitLds<NT, CC, IPC * G, NPL> lds;
     constexpr int S = CC / 32;                 // k-steps per item
     constexpr int CTT = 16 * NT, ACCLD = CTT + 4;
     constexpr int NCONS = NT / NTW;
@@ -196,7 +199,7 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
     // number of chunks = barrier intervals (uniform over the workgroup), padded to a multiple of the weight rotation
     int nch = 0;
     for (int kk = 0; kk < nnz; ++kk) nch += nsub(kk) * nchunk;
-    nch = (nch + WD - 1) / WD * WD;
+    nch = (nch + WD * G - 1) / (WD * G) * (WD * G);  // whole weight rotations and whole barrier intervals
     const ChunkIt it0{0, 0, 0};
     XM3D_STAMP(1);
 
@@ -210,79 +213,86 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
         // intervals while they land.
         const int p = wave - NCONS;
         const int g = __builtin_amdgcn_readfirstlane(p / NPW), m = __builtin_amdgcn_readfirstlane(p % NPW);
-        int a_src[IPP], a_dst[IPP], a_c;
-        bool a_ok[IPP];
-        f32x4 rows[IPP][NPL * S];
-        ChunkIt it_mine = it0;  // my group's next chunk
-        for (int i = 0; i < g; ++i) it_mine = next(it_mine);
+        int a_src[G * IPP], a_dst[G * IPP], a_c[G];
+        bool a_ok[G * IPP];
+        f32x4 rows[G * IPP][NPL * S];
+        ChunkIt it_mine = it0;  // my group's next interval (G chunks)
+        for (int i = 0; i < g * G; ++i) it_mine = next(it_mine);
 
-        auto stage_idx = [&]() __attribute__((always_inline)) {  // my items of the chunk at it_mine; it_mine += NG chunks
-            const ChunkIt t = it_mine;
-            const int kk = t.kk < 127 ? t.kk : 127;
-            const int cn = cntk(kk);  // 0 past the end
-            a_c = t.c;
-            const int64_t obase = (tbase + offk(kk)) * SROWS;
+        auto stage_idx = [&]() __attribute__((always_inline)) {  // my items of the G chunks at it_mine; it_mine += NG intervals
 #pragma unroll
-            for (int u = 0; u < IPP; ++u) {
-                const int pp = ((t.sub * IPC + m * IPP + u) << 4) + p16;
-                a_ok[u] = pp < cn;
-                // unconditional loads (clamped to a valid slot): no divergent branch, the predicate is applied on use
-                const int64_t o = obase + (a_ok[u] ? pp : 0);
-                a_src[u] = tsrc[o];
-                a_dst[u] = int(tdst[o]);
+            for (int gi = 0; gi < G; ++gi) {
+                const ChunkIt t = it_mine;
+                const int kk = t.kk < 127 ? t.kk : 127;
+                const int cn = cntk(kk);  // 0 past the end
+                a_c[gi] = t.c;
+                const int64_t obase = (tbase + offk(kk)) * SROWS;
+#pragma unroll
+                for (int u = 0; u < IPP; ++u) {
+                    const int pp = ((t.sub * IPC + m * IPP + u) << 4) + p16;
+                    a_ok[gi * IPP + u] = pp < cn;
+                    // unconditional loads (clamped to a valid slot): no divergent branch, the predicate is applied on use
+                    const int64_t o = obase + (a_ok[gi * IPP + u] ? pp : 0);
+                    a_src[gi * IPP + u] = tsrc[o];
+                    a_dst[gi * IPP + u] = int(tdst[o]);
+                }
+                it_mine = next(it_mine);
             }
-            ChunkIt n = t;
-#pragma unroll
-            for (int i = 0; i < NG; ++i) n = next(n);
-            it_mine = n;
+            for (int i = 0; i < (NG - 1) * G; ++i) it_mine = next(it_mine);
         };
         auto stage_rows = [&]() __attribute__((always_inline)) {  // indices -> row gathers in flight
 #pragma unroll
-            for (int u = 0; u < IPP; ++u) {
-                // padding slots read row 0 (valid memory); their MFMA columns are never accumulated (dst = -1)
-                const int64_t eo = int64_t(a_ok[u] ? a_src[u] : 0) * cin + a_c * CC + 8 * q;  // this lane's 8 channels per step
+            for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if constexpr (BF) {  // the one bf16 plane
-                        rows[u][s] = *reinterpret_cast<const f32x4*>(in_hi + eo + 32 * s);
-                    } else if constexpr (PRE) {  // ready-made bf16 hi / lo fragments
-                        rows[u][2 * s] = *reinterpret_cast<const f32x4*>(in_hi + eo + 32 * s);
-                        rows[u][2 * s + 1] = *reinterpret_cast<const f32x4*>(in_lo + eo + 32 * s);
-                    } else {
-                        rows[u][2 * s] = *reinterpret_cast<const f32x4*>(in + eo + 32 * s);
-                        rows[u][2 * s + 1] = *reinterpret_cast<const f32x4*>(in + eo + 32 * s + 4);
+                for (int u = 0; u < IPP; ++u) {
+                    const int x = gi * IPP + u;
+                    // padding slots read row 0 (valid memory); their MFMA columns are never accumulated (dst = -1)
+                    const int64_t eo = int64_t(a_ok[x] ? a_src[x] : 0) * cin + a_c[gi] * CC + 8 * q;  // this lane's 8 channels per step
+#pragma unroll
+                    for (int s = 0; s < S; ++s) {
+                        if constexpr (BF) {  // the one bf16 plane
+                            rows[x][s] = *reinterpret_cast<const f32x4*>(in_hi + eo + 32 * s);
+                        } else if constexpr (PRE) {  // ready-made bf16 hi / lo fragments
+                            rows[x][2 * s] = *reinterpret_cast<const f32x4*>(in_hi + eo + 32 * s);
+                            rows[x][2 * s + 1] = *reinterpret_cast<const f32x4*>(in_lo + eo + 32 * s);
+                        } else {
+                            rows[x][2 * s] = *reinterpret_cast<const f32x4*>(in + eo + 32 * s);
+                            rows[x][2 * s + 1] = *reinterpret_cast<const f32x4*>(in + eo + 32 * s + 4);
+                        }
                     }
                 }
-            }
         };
         auto stage_write = [&](int slot) __attribute__((always_inline)) {  // rows -> bf16 hi / lo fragments in the ring slot
 #pragma unroll
-            for (int u = 0; u < IPP; ++u) {
-                const int e = m * IPP + u;
+            for (int gi = 0; gi < G; ++gi)
 #pragma unroll
-                for (int s = 0; s < S; ++s) {
-                    if constexpr (BF) {
-                        lds.stage[slot][e][s][0][lane] = __builtin_bit_cast(uint4, rows[u][s]);
-                    } else if constexpr (PRE) {
-                        lds.stage[slot][e][s][0][lane] = __builtin_bit_cast(uint4, rows[u][2 * s]);
-                        lds.stage[slot][e][s][1][lane] = __builtin_bit_cast(uint4, rows[u][2 * s + 1]);
-                    } else {
-                        bf16x8 hi, lo;
+                for (int u = 0; u < IPP; ++u) {
+                    const int x = gi * IPP + u;
+                    const int e = gi * IPC + m * IPP + u;
 #pragma unroll
-                        for (int j = 0; j < 8; ++j) {
-                            const float x = rows[u][2 * s + (j >> 2)][j & 3];
-                            hi[j] = (__bf16)x;
-                            lo[j] = (__bf16)(x - (float)hi[j]);
+                    for (int s = 0; s < S; ++s) {
+                        if constexpr (BF) {
+                            lds.stage[slot][e][s][0][lane] = __builtin_bit_cast(uint4, rows[x][s]);
+                        } else if constexpr (PRE) {
+                            lds.stage[slot][e][s][0][lane] = __builtin_bit_cast(uint4, rows[x][2 * s]);
+                            lds.stage[slot][e][s][1][lane] = __builtin_bit_cast(uint4, rows[x][2 * s + 1]);
+                        } else {
+                            bf16x8 hi, lo;
+#pragma unroll
+                            for (int j = 0; j < 8; ++j) {
+                                const float xv = rows[x][2 * s + (j >> 2)][j & 3];
+                                hi[j] = (__bf16)xv;
+                                lo[j] = (__bf16)(xv - (float)hi[j]);
+                            }
+                            lds.stage[slot][e][s][0][lane] = __builtin_bit_cast(uint4, hi);
+                            lds.stage[slot][e][s][1][lane] = __builtin_bit_cast(uint4, lo);
                         }
-                        lds.stage[slot][e][s][0][lane] = __builtin_bit_cast(uint4, hi);
-                        lds.stage[slot][e][s][1][lane] = __builtin_bit_cast(uint4, lo);
                     }
+                    if (q == 0) lds.dst[slot][e][p16] = a_ok[x] ? a_dst[x] : -1;
                 }
-                if (q == 0) lds.dst[slot][e][p16] = a_ok[u] ? a_dst[u] : -1;
-            }
         };
-        // chunk 0 is published here by group 0 (its latency is paid once); every group then has its first loop chunk
-        // (chunk NG for group 0, chunk g for the others) in flight
+        // interval 0 is published here by group 0 (its latency is paid once); every group then has its first loop interval
+        // (interval NG for group 0, interval g for the others) in flight
         stage_idx();
         stage_rows();
         if (g == 0) {
@@ -293,18 +303,18 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
         XM3D_STAMP(2);
         __syncthreads();
         XM3D_STAMP(3);
-        int ph = (NG + 1 - g) % NG;  // phase of interval 0: interval ch publishes chunk ch + 1 = group (ch + 1) % NG
-        for (int ch = 0; ch < nch; ++ch) {
+        int ph = (NG + 1 - g) % NG;  // phase of interval 0: interval iv publishes interval iv + 1 = group (iv + 1) % NG
+        for (int iv = 0; iv < nch / G; ++iv) {
             if (ph == 0) {
-                stage_write((ch + 1) & 1);  // (past the end: an all-padding chunk nobody reads)
-                stage_idx();                // my next chunk: ch + 1 + NG
+                stage_write((iv + 1) & 1);  // (past the end: all-padding chunks nobody reads)
+                stage_idx();                // my next interval: iv + 1 + NG
             } else if (ph == 1 % NG) {
                 stage_rows();
             }
             ph = ph + 1 == NG ? 0 : ph + 1;
-            XM3D_STAMP(4 + 2 * ch);
+            XM3D_STAMP(4 + 2 * iv);
             __syncthreads();
-            XM3D_STAMP(5 + 2 * ch);
+            XM3D_STAMP(5 + 2 * iv);
         }
     } else {
         // ============================================================ consumer: output channels ct0 + 16 NTW wave .. + 16 NTW
@@ -355,7 +365,7 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
             static_for<WD>([&](auto PHc) __attribute__((always_inline)) {
                 constexpr int PH = decltype(PHc)::value;
                 const int ch = ch0 + PH;
-                const int slot = ch & 1;
+                const int slot = (ch / G) & 1, ib = (ch % G) * IPC;  // ring slot of the interval, first item of this chunk in it
                 load_w(std::integral_constant<int, (PH + 2) % WD>{}, it_w);  // chunk ch + 2 (its set was last used by chunk ch - 1)
                 it_w = next(it_w);
                 const int kk = it.kk < 127 ? it.kk : 127;
@@ -367,14 +377,14 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
                 f32x4 av[IPC][NTW];
 #pragma unroll
                 for (int e = 0; e < IPC; ++e) {
-                    drow[e] = lds.dst[slot][e][p16];
+                    drow[e] = lds.dst[slot][ib + e][p16];
                     if (e >= nitems) drow[e] = -1;
                 }
                 uint4 B[2][S][NPL];
 #pragma unroll
                 for (int s = 0; s < S; ++s)
 #pragma unroll
-                    for (int pl = 0; pl < NPL; ++pl) B[0][s][pl] = lds.stage[slot][0][s][pl][lane];
+                    for (int pl = 0; pl < NPL; ++pl) B[0][s][pl] = lds.stage[slot][ib][s][pl][lane];
 #pragma unroll
                 for (int e = 0; e < IPC; ++e)
 #pragma unroll
@@ -387,7 +397,7 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
 #pragma unroll
                         for (int s = 0; s < S; ++s)
 #pragma unroll
-                            for (int pl = 0; pl < NPL; ++pl) B[(e + 1) & 1][s][pl] = lds.stage[slot][e + 1][s][pl][lane];
+                            for (int pl = 0; pl < NPL; ++pl) B[(e + 1) & 1][s][pl] = lds.stage[slot][ib + e + 1][s][pl][lane];
                     }
                     if (e < nitems) {
                         f32x4 d[NTW];
@@ -415,9 +425,11 @@ __global__ __launch_bounds__(64 * (NT / NTW + NG * NPW)) void k_spconv_split(
                         }
                     }
                 }
-                XM3D_STAMP(4 + 2 * ch);
-                __syncthreads();
-                XM3D_STAMP(5 + 2 * ch);
+                if (G == 1 || ch % G == G - 1) {  // the interval's last chunk: hand the ring slot back (workgroup-uniform)
+                    XM3D_STAMP(4 + 2 * (ch / G));
+                    __syncthreads();
+                    XM3D_STAMP(5 + 2 * (ch / G));
+                }
             });
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the two weight sets requested past the end
@@ -602,22 +614,26 @@ extern "C" int xm3d_spconv_fwd_bf16(const void* in, int64_t n_in, int32_t cin, c
     const __bf16* in_b = static_cast<const __bf16*>(in);
     __bf16* o_b = ksplit > 1 ? nullptr : static_cast<__bf16*>(out);
     const float* res = static_cast<const float*>(residual);  // a bf16 plane (the kernel casts back)
-#define XM3D_BF(NT, NTW, CC, IPC, NG, NPW)                                                                                                   \
-    hipLaunchKernelGGL((k_spconv_split<NT, NTW, CC, IPC, NG, NPW, true, true>), grid, dim3(64 * (NT / NTW + NG * NPW)), 0, s, nullptr, in_b, \
-                       nullptr, o_b, nullptr, cin, wq, K, cout, tsrc, tdst, tcnt, order, n_out, scale, shift, res, relu, nullptr, ksplit, slab,  \
+#define XM3D_BF(NT, NTW, CC, IPC, NG, NPW, G_)                                                                                                   \
+    hipLaunchKernelGGL((k_spconv_split<NT, NTW, CC, IPC, NG, NPW, true, true, G_>), grid, dim3(64 * (NT / NTW + NG * NPW)), 0, s, nullptr, in_b, \
+                       nullptr, o_b, nullptr, cin, wq, K, cout, tsrc, tdst, tcnt, order, n_out, scale, shift, res, relu, nullptr, ksplit, slab,     \
                        ntiles)
+    // One chunk per barrier interval (G = 1).  G = 2 - 4 chunks per interval were measured and REJECTED (profiles/r04_spconv_bench.log: S1-full
+    // 96 -> 96 90.7 us against 84.2 us, every layer 0 - 8 % slower): the barrier is not what an interval waits for - the chain {pair indices ->
+    // row gather -> LDS publish} of the producer groups and the consumers' {row ids -> accumulator rows -> MFMA chain -> store} are
+    // per-chunk latencies that more chunks per interval do not shorten.  (The template keeps G for the next attempt.)
     if (ctt == 96) {
-        if (cc == 96) XM3D_BF(6, 1, 96, 4, 3, 2);
-        else if (cc == 64) XM3D_BF(6, 1, 64, 4, 3, 2);
-        else XM3D_BF(6, 1, 32, 8, 3, 2);
+        if (cc == 96) XM3D_BF(6, 1, 96, 4, 3, 2, 1);
+        else if (cc == 64) XM3D_BF(6, 1, 64, 4, 3, 2, 1);
+        else XM3D_BF(6, 1, 32, 8, 3, 2, 1);
     } else if (ctt == 64) {
-        if (cc == 96) XM3D_BF(4, 1, 96, 4, 3, 2);
-        else if (cc == 64) XM3D_BF(4, 1, 64, 8, 3, 2);
-        else XM3D_BF(4, 1, 32, 8, 3, 2);
+        if (cc == 96) XM3D_BF(4, 1, 96, 4, 3, 2, 1);
+        else if (cc == 64) XM3D_BF(4, 1, 64, 8, 3, 2, 1);
+        else XM3D_BF(4, 1, 32, 8, 3, 2, 1);
     } else {
-        if (cc == 96) XM3D_BF(2, 1, 96, 2, 3, 1);
-        else if (cc == 64) XM3D_BF(2, 1, 64, 4, 3, 1);
-        else XM3D_BF(2, 1, 32, 8, 3, 1);
+        if (cc == 96) XM3D_BF(2, 1, 96, 2, 3, 1, 1);
+        else if (cc == 64) XM3D_BF(2, 1, 64, 4, 3, 1, 1);
+        else XM3D_BF(2, 1, 32, 8, 3, 1, 1);
     }
 #undef XM3D_BF
     if (ksplit > 1) launch_slab_reduce(slab, ksplit, n_out, cout, scale, shift, nullptr, relu, nullptr, s, out, nullptr, residual);
