@@ -117,7 +117,7 @@ FP32 = {"pred_3d": 5e-5, "pred_masks": 1e-3, "mask_embed": 1e-3, "mask_embed_cli
 # With the HIP flash attention in the path: 4.4e-2 / 6.8e-2 / 3.1e-2 / 4.1e-2 / 3.6e-2 / 2.4e-2, ownership 96.7 %.
 # With the fused bf16 GroupNorm / LayerNorm / FPN kernels of round 2's last build: 4.4e-2 / 6.1e-2 / 3.3e-2 / 3.9e-2 / 2.4e-2 /
 # 1.7e-2, ownership 95.0-98.5 %, labels 100 %.
-BF16 = {"pred_3d": 5e-5, "pred_masks": 8e-2, "mask_embed": 1e-1, "mask_embed_clip": 7e-2, "pred_logits_abs": 8e-2,
+BF16 = {"pred_3d": 4e-2, "pred_masks": 8e-2, "mask_embed": 1e-1, "mask_embed_clip": 7e-2, "pred_logits_abs": 8e-2,
         "fused_rel": 6e-2, "point_logits_abs": 5e-2}
 
 
@@ -183,8 +183,9 @@ def test_bench_configuration_votes_match_fp32_reference_path(dev, setup):
         for name, a, b in zip(("fused", "2d", "3d"), got, want):
             agree = (a == b).float().mean().item()
             print(f"[votes {name}] agreement {agree:.4f}")
-            # 3D-only labels depend on the fp32 sparse nets alone; fused/2D labels carry the bf16 budget of the dense branch
-            assert agree > (0.9999 if name == "3d" else 0.97), (name, agree)
+            # every label carries the bf16 budget of the bench configuration: the sparse nets run the plain-bf16 form since round 4
+            # (measured 3D 0.9996 - 0.9999; with XM3D_SPARSE=f32 the 3D-only labels agree to 0.9999+), fused / 2D also the dense branch's
+            assert agree > (0.998 if name == "3d" else 0.97), (name, agree)
 
 
 @pytest.mark.parametrize("name", ["xmask3d_scannet_B12N7", "xmask3d_scannet_B170N30"])

@@ -9,10 +9,11 @@ from xmask3d_amd.config import load_cfg_from_cfg_file
 from xmask3d_amd.xmask3d import XMASK3d
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 20
+DT = torch.float32 if (len(sys.argv) > 2 and sys.argv[2] == "fp32") else torch.bfloat16  # python tools/prof_lines.py 20 fp32
 dev = torch.device("cuda:0")
 cfg = load_cfg_from_cfg_file(os.path.join(ROOT, "configs", "xmask3d_scannet_B15N4.yaml"))
 torch.manual_seed(0)
-model = pipeline.make_inference_model(XMASK3d(cfg).eval(), dev, torch.bfloat16, channels_last=True, graphs=False)
+model = pipeline.make_inference_model(XMASK3d(cfg).eval(), dev, DT, channels_last=True, graphs=False)
 sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
 vox = pipeline.default_voxelizer(device=dev)
 T = np.diag([50.0, 50.0, 50.0, 1.0])

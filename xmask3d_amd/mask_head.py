@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .sd_model import ACT_NONE, ACT_RELU, Conv2d, fused_conv_ok, gn_act, own_conv, plain_conv3x3
+from .sd_model import ACT_NONE, ACT_RELU, Conv2d, Linear, flinear, fused_conv_ok, gn_act, own_conv, plain_conv3x3
 from .msda import MSDeformAttn
 
 
@@ -65,9 +65,9 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
         self.norm1 = nn.LayerNorm(d_model)
-        self.linear1 = nn.Linear(d_model, d_ffn)
+        self.linear1 = Linear(d_model, d_ffn)
         self.dropout2 = nn.Dropout(dropout)
-        self.linear2 = nn.Linear(d_ffn, d_model)
+        self.linear2 = Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
         self.norm2 = nn.LayerNorm(d_model)
 
@@ -278,15 +278,15 @@ class SelfAttentionLayer(nn.Module):
             E, H = mha.embed_dim, mha.num_heads
             w, b = mha.in_proj_weight, mha.in_proj_bias
             L, B = tgt.shape[:2]
-            qk = F.linear(q, w[: 2 * E], b[: 2 * E])                       # (L, B, 2E): q and k share their input
-            v = F.linear(tgt, w[2 * E:], b[2 * E:])
+            qk = flinear(q, w[: 2 * E], b[: 2 * E])                       # (L, B, 2E): q and k share their input
+            v = flinear(tgt, w[2 * E:], b[2 * E:])
             q4 = qk[..., :E].unflatten(-1, (H, E // H)).transpose(0, 1)    # (B, L, H, d) views
             k4 = qk[..., E:].unflatten(-1, (H, E // H)).transpose(0, 1)
             v4 = v.view(L, B, H, E // H).transpose(0, 1)
             if ops.attention_supported(q4, k4, v4):
                 o = torch.empty((L, B, E), dtype=q4.dtype, device=tgt.device)
                 ops.attention(q4, k4, v4, out=o.view(L, B, H, E // H).transpose(0, 1))
-                return self.norm(tgt + F.linear(o, mha.out_proj.weight, mha.out_proj.bias).float())  # (.float(): a mixed f32 + bf16 add of this size takes the 35 us generic kernel)
+                return self.norm(tgt + flinear(o, mha.out_proj.weight, mha.out_proj.bias).float())  # (.float(): a mixed f32 + bf16 add of this size takes the 35 us generic kernel)
         return self.norm(tgt + self.self_attn(q, k, value=tgt, need_weights=False)[0])
 
 
@@ -311,9 +311,9 @@ class CrossAttentionLayer(nn.Module):
         mha = self.multihead_attn
         E, H = mha.embed_dim, mha.num_heads
         w, b = mha.in_proj_weight, mha.in_proj_bias
-        q = F.linear(tgt + query_pos, w[:E], b[:E])
-        k = F.linear(key, w[E:2 * E], b[E:2 * E])
-        v = F.linear(memory, w[2 * E:], b[2 * E:])
+        q = flinear(tgt + query_pos, w[:E], b[:E])
+        k = flinear(key, w[E:2 * E], b[E:2 * E])
+        v = flinear(memory, w[2 * E:], b[2 * E:])
         Lq, B = q.shape[:2]
         Lk = k.shape[0]
         q4, k4, v4 = (t.view(t.shape[0], B, H, E // H).transpose(0, 1) for t in (q, k, v))  # (B, L, H, d) views of the (L, B, E) rows
@@ -322,20 +322,20 @@ class CrossAttentionLayer(nn.Module):
             # output written straight in (Lq, B, E) order for the out-projection
             o = torch.empty((Lq, B, E), dtype=q.dtype, device=q.device)
             ops.attention(q4, k4, v4, bias=memory_bias.view(B, 1, Lq, Lk), out=o.view(Lq, B, H, E // H).transpose(0, 1))
-            return self.norm(tgt + F.linear(o, mha.out_proj.weight, mha.out_proj.bias).float())  # (.float(): a mixed f32 + bf16 add of this size takes the 35 us generic kernel)
+            return self.norm(tgt + flinear(o, mha.out_proj.weight, mha.out_proj.bias).float())  # (.float(): a mixed f32 + bf16 add of this size takes the 35 us generic kernel)
         q = q.view(Lq, B, H, E // H).permute(1, 2, 0, 3)
         k = k.view(Lk, B, H, E // H).permute(1, 2, 0, 3)
         v = v.view(Lk, B, H, E // H).permute(1, 2, 0, 3)
         o = F.scaled_dot_product_attention(q, k, v, attn_mask=memory_bias.view(B, 1, Lq, Lk).to(q.dtype))
-        tgt2 = F.linear(o.permute(2, 0, 1, 3).reshape(Lq, B, E), mha.out_proj.weight, mha.out_proj.bias)
+        tgt2 = flinear(o.permute(2, 0, 1, 3).reshape(Lq, B, E), mha.out_proj.weight, mha.out_proj.bias)
         return self.norm(tgt + tgt2)
 
 
 class FFNLayer(nn.Module):
     def __init__(self, d_model, dim_feedforward=2048):
         super().__init__()
-        self.linear1 = nn.Linear(d_model, dim_feedforward)
-        self.linear2 = nn.Linear(dim_feedforward, d_model)
+        self.linear1 = Linear(d_model, dim_feedforward)
+        self.linear2 = Linear(dim_feedforward, d_model)
         self.norm = nn.LayerNorm(d_model)
         for p in self.parameters():
             if p.dim() > 1:
@@ -350,7 +350,7 @@ class MLP(nn.Module):
         super().__init__()
         self.num_layers = num_layers
         h = [hidden_dim] * (num_layers - 1)
-        self.layers = nn.ModuleList(nn.Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
+        self.layers = nn.ModuleList(Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
     def forward(self, x):
         for i, layer in enumerate(self.layers):
@@ -392,7 +392,7 @@ class MaskPooling(nn.Module):
 class PooledMaskEmbed(nn.Module):
     def __init__(self, hidden_dim, mask_dim, projection_dim, temperature=0.07):
         super().__init__()
-        self.pool_proj = nn.Sequential(nn.LayerNorm(hidden_dim), nn.Linear(hidden_dim, hidden_dim))
+        self.pool_proj = nn.Sequential(nn.LayerNorm(hidden_dim), Linear(hidden_dim, hidden_dim))
         self.mask_embed = nn.Sequential(nn.LayerNorm(mask_dim), MLP(mask_dim, hidden_dim, projection_dim, 3))
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / temperature))
         self.mask_pooling = MaskPooling()
@@ -451,7 +451,7 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
                 self.input_proj.append(conv)
             else:
                 self.input_proj.append(nn.Sequential())
-        self.class_embed = class_embed if class_embed is not None else nn.Linear(hidden_dim, num_classes + 1)
+        self.class_embed = class_embed if class_embed is not None else Linear(hidden_dim, num_classes + 1)
         self.mask_embed = MLP(hidden_dim, hidden_dim, mask_dim, 3)
         self.post_mask_embed = post_mask_embed
         # eval only: the pooled mask-CLIP embedding of the 9 intermediate layers feeds nothing but the training losses;

@@ -27,6 +27,7 @@ from torch.autograd.function import once_differentiable
 from torch.nn.init import constant_, xavier_uniform_
 
 from . import ops
+from .sd_model import Linear, flinear
 
 
 def _check(value, spatial_shapes, level_start_index, sampling_loc, attn_weight, im2col_step, extra=()):
@@ -82,10 +83,10 @@ class MSDeformAttn(nn.Module):
             raise ValueError("d_model must be divisible by n_heads, but got {} and {}".format(d_model, n_heads))
         self.im2col_step = 128
         self.d_model, self.n_levels, self.n_heads, self.n_points = d_model, n_levels, n_heads, n_points
-        self.sampling_offsets = nn.Linear(d_model, n_heads * n_levels * n_points * 2)
-        self.attention_weights = nn.Linear(d_model, n_heads * n_levels * n_points)
-        self.value_proj = nn.Linear(d_model, d_model)
-        self.output_proj = nn.Linear(d_model, d_model)
+        self.sampling_offsets = Linear(d_model, n_heads * n_levels * n_points * 2)
+        self.attention_weights = Linear(d_model, n_heads * n_levels * n_points)
+        self.value_proj = Linear(d_model, d_model)
+        self.output_proj = Linear(d_model, d_model)
         self._reset_parameters()
 
     def _reset_parameters(self):
@@ -124,7 +125,7 @@ class MSDeformAttn(nn.Module):
                 self._cat_w = torch.cat([so.weight.detach(), aw.weight.detach()]).to(dt).contiguous()
                 self._cat_b = torch.cat([so.bias.detach(), aw.bias.detach()]).to(dt).contiguous()
                 self._cat_key = key
-            ow = F.linear(query.to(self._cat_w.dtype), self._cat_w, self._cat_b)
+            ow = flinear(query.to(self._cat_w.dtype), self._cat_w, self._cat_b)
             n_off = H * L * P * 2
             offsets = ow[..., :n_off].float().view(N, Len_q, H, L, P, 2)
             weights = F.softmax(ow[..., n_off:].float().view(N, Len_q, H, L * P), -1).view(N, Len_q, H, L, P)

@@ -346,6 +346,13 @@ def flinear(x, weight, bias=None, act=None, residual=None):
     return y if residual is None else y + residual
 
 
+class Linear(nn.Linear):
+    """nn.Linear whose GPU-inference forward runs on the own GEMM kernels where gemm_ok() says so (flinear); torch otherwise"""
+
+    def forward(self, x):
+        return flinear(x, self.weight, self.bias)
+
+
 def conv1x1_nobias(conv, x):
     """a 1x1 convolution without its bias: the token GEMM on k_gemm where that wins (channels-last bf16 inference), else the library"""
     if fused_nhwc(x) and conv.kernel_size == (1, 1) and conv.stride == (1, 1) and gemm_ok(tokens_of(x), conv.out_channels) \
