@@ -440,6 +440,14 @@ int xm3d_attention_fwd(const void* q, const void* k, const void* v, void* out, i
 int xm3d_attention_fwd_lse(const void* q, const void* k, const void* v, void* out, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t D,
                            const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
                            const void* bias, int32_t bias_dtype, const int64_t* bias_strides, float scale, float* lse2, void* stream);
+/* The same attention to f32 ACCURACY on the 16-bit matrix cores (attention_f32.hip) - the fp32 configuration (the reference's own
+ * arithmetic: f32 torch attention, run/train.py:178 - no autocast): q, k, v, out f32 with element strides as above (multiples of 4),
+ * bias NULL or additive f32.  Both products run on operands split in IEEE halves (22 mantissa bits, three MFMAs per product, leading
+ * and small terms in separate f32 accumulators), the softmax in f32; nothing of size Nq x Nk touches memory (torch's MATH path wrote
+ * a 10.7 GB score tensor per 64^2 self attention of 20 views).  Head channels a multiple of 8 up to 64. */
+int xm3d_attention_fwd_f32(const float* q, const float* k, const float* v, float* out, int32_t B, int32_t H, int32_t Nq, int32_t Nk, int32_t D,
+                           const int64_t* q_strides, const int64_t* k_strides, const int64_t* v_strides, const int64_t* o_strides,
+                           const float* bias, const int64_t* bias_strides, float scale, void* stream);
 /* Backward of the attention above (attention_bwd.hip): dq (B,Nq,H,D), dk / dv (B,Nk,H,D) bf16 CONTIGUOUS outputs, from q, k, v, the
  * forward's out and lse2, and dout (the gradient w.r.t. out; element strides like the other operands).  The additive bias is a
  * constant (no gradient).  delta_ws: B*H*Nq floats of scratch.  Replaces autograd through the reference's attention

@@ -267,3 +267,67 @@ def test_attention_backward_is_reproducible_and_used_by_the_unet(dev):
     finally:
         ops.attention_train = orig
     assert seen and ctx.grad is not None and float(ctx.grad.abs().sum()) > 0
+
+
+# ---------------------------------------------------------------- f32-accurate attention (attention_f32.hip)
+def _ref64(q, k, v, bias, scale):
+    q, k, v = (t.double().permute(0, 2, 1, 3) for t in (q, k, v))
+    s = (q @ k.transpose(-1, -2)) * scale
+    if bias is not None:
+        s = s + bias.double()
+    return (torch.softmax(s, -1).nan_to_num(0.0) @ v).permute(0, 2, 1, 3)
+
+
+@pytest.mark.parametrize("B,H,Nq,Nk,D", [(2, 8, 4096, 4096, 40), (2, 8, 4096, 77, 40), (2, 16, 257, 257, 64), (2, 8, 50, 1024, 32),
+                                         (1, 2, 33, 65, 8), (1, 1, 1, 1, 16), (1, 3, 130, 191, 48), (2, 4, 100, 64, 24)])
+def test_attention_f32_matches_f64_reference(dev, B, H, Nq, Nk, D):
+    """xm3d_attention_fwd_f32 (operands split in IEEE halves, three MFMAs per product, f32 softmax) against an f64 softmax attention:
+    bound 2e-6 of max|out| - what torch's own f32 MATH attention reaches on the same inputs (measured beside it)."""
+    from xmask3d_amd import ops
+
+    g = torch.Generator().manual_seed(B * 1000 + Nq + Nk + D)
+    q = (torch.randn(B, Nq, H * D, generator=g) * 1.5).to(dev).view(B, Nq, H, D)
+    k = (torch.randn(B, Nk, H * D, generator=g) * 1.5).to(dev).view(B, Nk, H, D)
+    v = (torch.randn(B, Nk, H * D, generator=g) * torch.logspace(-2, 1.5, H * D)).to(dev).view(B, Nk, H, D)
+    assert ops.attention_f32_supported(q, k, v)
+    out = ops.attention_f32(q, k, v)
+    assert out.shape == (B, Nq, H, D) and out.dtype == torch.float32 and torch.equal(out, ops.attention_f32(q, k, v))
+    ref = _ref64(q, k, v, None, D ** -0.5)
+    err = float((out.double() - ref).abs().max() / ref.abs().max())
+    lib_err = float((_ref(q, k, v, None, D ** -0.5).permute(0, 2, 1, 3).double() - ref).abs().max() / ref.abs().max())
+    assert err < 2e-6, (err, lib_err)
+    if Nk > 64:  # a key that dominates late: the running-maximum rescale across tiles, scores of magnitude ~100
+        k2 = k.clone()
+        k2[:, Nk - 3] = q[:, 0:1].expand(-1, 1, -1, -1).reshape(B, H, D) * 4
+        ref2 = _ref64(q, k2, v, None, D ** -0.5)
+        assert float((ops.attention_f32(q, k2, v).double() - ref2).abs().max() / ref2.abs().max()) < 2e-6
+
+
+def test_attention_f32_masks_strides_and_output_views(dev):
+    """packed (B, T, 3, H, D) qkv views, additive f32 mask with -inf entries and a fully masked row (-> zeros), broadcast over heads,
+    output written into a transposed (L, B, E) buffer as the decoder layers do"""
+    from xmask3d_amd import ops
+
+    B, T, H, D, Qn = 3, 257, 16, 64, 50
+    g = torch.Generator().manual_seed(11)
+    qkv = torch.randn(B, T, 3, H, D, generator=g).to(dev)
+    bias = torch.zeros(B, 1, T, T)
+    bias[:, :, :, :Qn] = float("-inf")
+    bias[:, :, :Qn, Qn + 1:].masked_fill_(torch.rand(B, 1, Qn, T - Qn - 1, generator=g) < 0.7, float("-inf"))
+    bias[1, 0, 5, :] = float("-inf")  # a fully masked row
+    bias = bias.to(dev)
+    q, k, v = qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]
+    assert ops.attention_f32_supported(q, k, v, bias)
+    out = ops.attention_f32(q, k, v, bias=bias)
+    ref = _ref64(q, k, v, bias, D ** -0.5)
+    assert float((out.double() - ref).abs().max() / ref.abs().max()) < 2e-6
+    assert float(out[1, 5].abs().max()) == 0.0
+    # decoder layout: (L, B, E) rows viewed as (B, L, H, d), bias (B, 1, Lq, Lk) shared by the heads
+    Lq, Lk, E, Hd = 50, 1024, 256, 8
+    qd, kd, vd = (torch.randn(n, B, E, generator=g).to(dev).view(n, B, Hd, E // Hd).transpose(0, 1) for n in (Lq, Lk, Lk))
+    mb = torch.where(torch.rand(B, 1, Lq, Lk, generator=g) < 0.5, 0.0, float("-inf")).to(dev)
+    o = torch.empty(Lq, B, E, device=dev)
+    ops.attention_f32(qd, kd, vd, bias=mb, out=o.view(Lq, B, Hd, E // Hd).transpose(0, 1))
+    refd = _ref64(qd, kd, vd, mb, (E // Hd) ** -0.5)
+    assert float((o.view(Lq, B, Hd, E // Hd).transpose(0, 1).double() - refd).abs().max() / refd.abs().max()) < 2e-6
+    assert not ops.attention_f32_supported(torch.zeros(1, 4, 2, 80, device=dev), torch.zeros(1, 4, 2, 80, device=dev), torch.zeros(1, 4, 2, 80, device=dev))

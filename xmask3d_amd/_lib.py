@@ -94,6 +94,7 @@ _SIGS = {
                                         ctypes.c_float, ctypes.c_float, c_vp, c_vp]),
     "xm3d_attention_fwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                           ctypes.c_float, c_vp]),
+    "xm3d_attention_fwd_f32": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, ctypes.c_float, c_vp]),
     "xm3d_attention_fwd_lse": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_vp,
                                               ctypes.c_float, c_vp, c_vp]),
     "xm3d_attention_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_vp, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp, c_vp,

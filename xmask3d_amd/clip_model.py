@@ -65,6 +65,13 @@ class ResidualAttentionBlock(nn.Module):
                 bias = bias[None, None]
             o = ops.attention(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], bias=bias)
             return flinear(o.view(b, t, c), self.attn.out_proj.weight, self.attn.out_proj.bias)
+        if ops.attention_f32_supported(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2]):
+            # fp32 configuration: the f32-accurate flash attention on the packed qkv buffer
+            bias = allow if (allow is None or allow.dtype != torch.bool) else additive_mask(allow, x.dtype)
+            if bias is not None and bias.dim() == 2:
+                bias = bias[None, None]
+            o = ops.attention_f32(qkv[:, :, 0], qkv[:, :, 1], qkv[:, :, 2], bias=bias)
+            return flinear(o.view(b, t, c), self.attn.out_proj.weight, self.attn.out_proj.bias)
         q, k, v = qkv.permute(2, 0, 3, 1, 4)
         if allow is not None and allow.dtype != torch.bool:
             allow = allow.to(q.dtype)
@@ -98,7 +105,7 @@ class Transformer(nn.Module):
         self.resblocks = nn.ModuleList(ResidualAttentionBlock(width, heads) for _ in range(layers))
 
     def forward(self, x, allow=None):
-        if allow is not None and allow.dtype == torch.bool and x.is_cuda and x.dtype == torch.bfloat16 and not torch.is_grad_enabled():
+        if allow is not None and allow.dtype == torch.bool and x.is_cuda and x.dtype in (torch.bfloat16, torch.float32) and not torch.is_grad_enabled():
             allow = additive_mask(allow, x.dtype)  # once for all layers (the HIP attention takes the additive form)
         for blk in self.resblocks:
             x = blk(x, allow)

@@ -272,7 +272,7 @@ class SelfAttentionLayer(nn.Module):
     def forward(self, tgt, query_pos=None):
         q = k = tgt + query_pos
         mha = self.self_attn
-        if tgt.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled("cuda"):
+        if tgt.is_cuda and not torch.is_grad_enabled() and (torch.is_autocast_enabled("cuda") or mha.in_proj_weight.dtype == torch.float32):
             # bf16 inference (autocast region of XMASK3d._decode_heads): the projections nn.MultiheadAttention runs, HIP flash
             # attention in between (xm3d_attention_fwd)
             E, H = mha.embed_dim, mha.num_heads
@@ -287,6 +287,10 @@ class SelfAttentionLayer(nn.Module):
                 o = torch.empty((L, B, E), dtype=q4.dtype, device=tgt.device)
                 ops.attention(q4, k4, v4, out=o.view(L, B, H, E // H).transpose(0, 1))
                 return self.norm(tgt + flinear(o, mha.out_proj.weight, mha.out_proj.bias).float())  # (.float(): a mixed f32 + bf16 add of this size takes the 35 us generic kernel)
+            if ops.attention_f32_supported(q4, k4, v4):  # fp32 configuration: the f32-accurate flash attention, same data flow
+                o = torch.empty((L, B, E), dtype=torch.float32, device=tgt.device)
+                ops.attention_f32(q4, k4, v4, out=o.view(L, B, H, E // H).transpose(0, 1))
+                return self.norm(tgt + flinear(o, mha.out_proj.weight, mha.out_proj.bias))
         return self.norm(tgt + self.self_attn(q, k, value=tgt, need_weights=False)[0])
 
 
@@ -323,6 +327,10 @@ class CrossAttentionLayer(nn.Module):
             o = torch.empty((Lq, B, E), dtype=q.dtype, device=q.device)
             ops.attention(q4, k4, v4, bias=memory_bias.view(B, 1, Lq, Lk), out=o.view(Lq, B, H, E // H).transpose(0, 1))
             return self.norm(tgt + flinear(o, mha.out_proj.weight, mha.out_proj.bias).float())  # (.float(): a mixed f32 + bf16 add of this size takes the 35 us generic kernel)
+        if ops.attention_f32_supported(q4, k4, v4) and memory_bias.dtype == torch.float32:  # fp32 configuration
+            o = torch.empty((Lq, B, E), dtype=torch.float32, device=q.device)
+            ops.attention_f32(q4, k4, v4, bias=memory_bias.view(B, 1, Lq, Lk), out=o.view(Lq, B, H, E // H).transpose(0, 1))
+            return self.norm(tgt + flinear(o, mha.out_proj.weight, mha.out_proj.bias))
         q = q.view(Lq, B, H, E // H).permute(1, 2, 0, 3)
         k = k.view(Lk, B, H, E // H).permute(1, 2, 0, 3)
         v = v.view(Lk, B, H, E // H).permute(1, 2, 0, 3)

@@ -1137,6 +1137,48 @@ def attention(q, k, v, bias=None, scale=None, out=None):
     return out
 
 
+def attention_f32_supported(q, k, v, bias=None):
+    """True when xm3d_attention_fwd_f32 takes these tensors as they are: f32 device tensors (B,N,H,D), channels contiguous, 16-byte
+    rows, D a multiple of 8 up to 64, no gradient wanted, bias None or additive f32 (B|1, H|1, Nq, Nk)"""
+    if _ATTENTION_OFF or _os.environ.get("XM3D_ATTENTION_F32", "hip") == "library" or torch.is_grad_enabled():
+        return False
+    for t in (q, k, v):
+        if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4 or t.stride(3) != 1 or t.data_ptr() % 16:
+            return False
+        if any(st % 4 for st in t.stride()[:3]):
+            return False
+    D = q.shape[3]
+    if D % 8 or D > 64 or k.shape[3] != D or v.shape[3] != D or k.shape[1] != v.shape[1] or k.shape[1] < 1:
+        return False
+    if bias is not None and (not bias.is_cuda or bias.dtype != torch.float32 or bias.dim() != 4 or bias.stride(3) != 1):
+        return False
+    return True
+
+
+def attention_f32(q, k, v, bias=None, scale=None, out=None):
+    """softmax(q k^T * scale + bias) v per (batch, head) to f32 accuracy on the matrix cores (csrc/attention_f32.hip: operands split
+    in IEEE halves, f32 softmax).  q (B,Nq,H,D), k/v (B,Nk,H,D) f32 views with contiguous channels; bias None or additive f32
+    (B|1, H|1, Nq, Nk), -inf masks.  -> out (B,Nq,H,D) f32 (fresh contiguous, or the given view)."""
+    B, Nq, H, D = q.shape
+    Nk = k.shape[1]
+    if out is None:
+        out = torch.empty((B, Nq, H, D), dtype=torch.float32, device=q.device)
+    if scale is None:
+        scale = D ** -0.5
+
+    def st(t):
+        return (ctypes.c_int64 * 3)(t.stride(0), t.stride(1), t.stride(2))
+
+    bst = None
+    if bias is not None:
+        if bias.shape[-2:] != (Nq, Nk) or bias.shape[0] not in (1, B) or bias.shape[1] not in (1, H):
+            raise RuntimeError(f"attention_f32: bias shape {tuple(bias.shape)} does not broadcast to ({B},{H},{Nq},{Nk})")
+        bst = (ctypes.c_int64 * 3)(bias.stride(0) if bias.shape[0] > 1 else 0, bias.stride(1) if bias.shape[1] > 1 else 0, bias.stride(2))
+    check(lib().xm3d_attention_fwd_f32(_ptr(q), _ptr(k), _ptr(v), _ptr(out), B, H, Nq, Nk, D, st(q), st(k), st(v), st(out), _ptr(bias), bst,
+                                       float(scale), _stream()), "xm3d_attention_fwd_f32")
+    return out
+
+
 def _att_ok(q, k, v, bias):
     for t in (q, k, v):
         if not t.is_cuda or t.dtype != torch.bfloat16 or t.dim() != 4 or t.stride(3) != 1 or t.data_ptr() % 16:

@@ -713,8 +713,11 @@ class CrossAttention(nn.Module):
                 k, v = (kv[..., i * inner:(i + 1) * inner].unflatten(-1, (h, -1)) for i in range(2))
             if ops.attention_supported(q, k, v):
                 return lin(self.to_out[0], ops.attention(q, k, v).view(b, n, -1))
-            if x.dtype == torch.float32:  # fp32 configuration: f32-accurate projections around torch's MATH attention
-                o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).reshape(b, n, -1)
+            if x.dtype == torch.float32:  # fp32 configuration: f32-accurate projections around the f32-accurate attention
+                if ops.attention_f32_supported(q, k, v):
+                    o = ops.attention_f32(q, k, v).view(b, n, -1)
+                else:  # head dims > 64 (the <= 1024-token levels): torch's MATH attention
+                    o = F.scaled_dot_product_attention(q.transpose(1, 2), k.transpose(1, 2), v.transpose(1, 2)).transpose(1, 2).reshape(b, n, -1)
                 return lin(self.to_out[0], o)
         q = self.to_q(x).view(b, n, h, -1)
         k = self.to_k(context).view(b, context.shape[1], h, -1)
