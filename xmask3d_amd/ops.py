@@ -1140,7 +1140,8 @@ def attention(q, k, v, bias=None, scale=None, out=None):
 def attention_f32_supported(q, k, v, bias=None):
     """True when xm3d_attention_fwd_f32 takes these tensors as they are: f32 device tensors (B,N,H,D), channels contiguous, 16-byte
     rows, D a multiple of 8 up to 64, no gradient wanted, bias None or additive f32 (B|1, H|1, Nq, Nk)"""
-    if _ATTENTION_OFF or _os.environ.get("XM3D_ATTENTION_F32", "hip") == "library" or torch.is_grad_enabled():
+    if _ATTENTION_OFF or _os.environ.get("XM3D_ATTENTION_F32", "hip") == "library" or \
+            (torch.is_grad_enabled() and (q.requires_grad or k.requires_grad or v.requires_grad)):
         return False
     for t in (q, k, v):
         if not t.is_cuda or t.dtype != torch.float32 or t.dim() != 4 or t.stride(3) != 1 or t.data_ptr() % 16:
