@@ -40,9 +40,10 @@ with torch.no_grad():
         model.dense_forward(batch["img"], cond)
         torch.cuda.synchronize()
 skip = ("convolution", "mm", "bmm", "linear", "layer_norm", "group_norm", "attention", "softmax", "MSDeform", "conv2d", "matmul")
+ONLY_LIB = "lib" in sys.argv[2:]  # python tools/prof_lines.py 20 fp32 lib: the library GEMMs / convolutions / norms instead (who still calls them)
 acc = collections.defaultdict(lambda: [0.0, 0])
 for e in prof.events():
-    if not e.name.startswith("aten::") or any(k in e.name for k in skip):
+    if not e.name.startswith("aten::") or (any(k in e.name for k in skip) != ONLY_LIB):
         continue
     t = e.self_device_time_total
     if t <= 0:

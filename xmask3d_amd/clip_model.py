@@ -86,7 +86,7 @@ class ResidualAttentionBlock(nn.Module):
             # inference: HIP LayerNorm (xm3d_layer_norm); the residual add in front of ln_2 rides in its kernel
             a = self.attention(ops.layer_norm(x, n1.weight, n1.bias, n1.eps), allow)
             h, x = ops.layer_norm(x, n2.weight, n2.bias, n2.eps, delta=a.contiguous(), want_sum=True)
-            return x + self.mlp(h)
+            return self._mlp_res(h, x)
         x = x + self.attention(self.ln_1(x), allow)
         return self._mlp_res(self.ln_2(x), x)
 

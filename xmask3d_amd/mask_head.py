@@ -157,9 +157,11 @@ class _Conv(nn.Conv2d):
         """residual: added after the norm, before the ReLU (the FPN's top-down term rides in the GroupNorm apply pass)"""
         x = self._conv(x)
         if self._gn:
-            if _fused_inference(x):
+            if _fused_inference(x) or (_fused_inference(x, torch.float32) and self.norm.weight.dtype == torch.float32
+                                       and (residual is None or residual.dtype == torch.float32)):
                 # bf16 inference under autocast: the fused channels-last GroupNorm(+residual)(+ReLU) kernel, bf16 out - the
-                # next convolution would round torch's f32 GroupNorm output to bf16 anyway
+                # next convolution would round torch's f32 GroupNorm output to bf16 anyway.  f32 (the fp32 configuration): the same
+                # kernel in f32 - two passes instead of the library's five, the moments from the convolution's epilogue when it left them
                 return gn_act(self.norm, x, ACT_RELU if self._relu else ACT_NONE, residual=residual)
             x = self.norm(x)
         if residual is not None:
@@ -168,18 +170,22 @@ class _Conv(nn.Conv2d):
 
 
 def _head_conv(conv, x):
-    """a convolution of the pixel decoder on the own kernels where they apply (channels-last bf16 inference with bf16 weight copies:
-    cast_head_weights): the 3x3 output convolutions on the halo-tile kernel - the moments of the result for the GroupNorm behind it
-    come out of the epilogue - the 1x1 lateral / projection convolutions on the implicit-GEMM kernel.  None: use torch."""
-    if not (_fused_inference(x) and conv.weight.dtype == torch.bfloat16):
+    """a convolution of the pixel decoder on the own kernels where they apply: channels-last inference with bf16 activations and bf16
+    weight copies (cast_head_weights), or f32 activations and weights (the fp32 configuration: the f32-accurate forms).  The 3x3 output
+    convolutions run on the halo-tile kernel - the moments of the result for the GroupNorm behind it come out of the epilogue - the 1x1
+    lateral / projection convolutions on the implicit-GEMM kernel.  None: use torch."""
+    if not (x.is_cuda and not torch.is_grad_enabled() and x.dim() == 4 and not x.is_contiguous()
+            and x.is_contiguous(memory_format=torch.channels_last)):
+        return None
+    if not ((x.dtype == torch.bfloat16 and conv.weight.dtype == torch.bfloat16) or (x.dtype == torch.float32 and conv.weight.dtype == torch.float32)):
         return None
     if conv.kernel_size == (3, 3) and fused_conv_ok(x, conv):
         return plain_conv3x3(conv, x)
     return own_conv(conv, x)
 
 
-def _fused_inference(x):
-    return x.is_cuda and not torch.is_grad_enabled() and x.dtype == torch.bfloat16 and x.dim() == 4 \
+def _fused_inference(x, dtype=torch.bfloat16):
+    return x.is_cuda and not torch.is_grad_enabled() and x.dtype == dtype and x.dim() == 4 \
         and not x.is_contiguous() and x.is_contiguous(memory_format=torch.channels_last)
 
 
