@@ -349,6 +349,16 @@ int xm3d_gemm_f32acc(const void* x, int64_t M, int32_t K, int64_t ldx, const voi
                      float alpha, const float* accin, const float* residual, int64_t ldr, float* out, int64_t ldo, int32_t waves, int32_t conv,
                      int64_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho,
                      int32_t Wo, void* stream);
+/* The same product in ONE launch (gemm.hip GF_SPLIT3): both half planes of x and both packed half images of W, three MFMAs per k-step into
+ * one accumulator.  Needs both terms of an operand at ONE scale (xm3d_split_f16t_nhwc: x s = hi + lo): alpha = 1 / (s t).
+ *     out (f32) = act( alpha * (x_hi W_hi^T + x_hi W_lo^T + x_lo W_hi^T) + bias ) + residual
+ * A third of the token / output traffic and launches of the three accumulating passes; range |x| s <= 65504 (sticky flag beyond). */
+int xm3d_split_f16t_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
+                         const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, float scale_hi, void* hi, void* lo,
+                         void* ws, void* stream);
+int xm3d_gemm_f32(const void* x_hi, const void* x_lo, int64_t M, int32_t K, int64_t ldx, const void* wp_hi, const void* wp_lo, int32_t N, const float* bias,
+                  int32_t act, float alpha, const float* residual, int64_t ldr, float* out, int64_t ldo, int32_t waves, int32_t conv, int64_t B, int32_t Hin,
+                  int32_t Win, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, void* stream);
 /* GroupNorm moments alone, in the layout the calls above take: stats[0 .. B*G*2) f64 <- (sum, sum of squares) of x (+ shift) per
  * (sample, group); x (B, H*W, C) channels-last, dtype 0 = f32 / 1 = bf16; stats holds xm3d_gn_stats_doubles_nhwc doubles. */
 int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,

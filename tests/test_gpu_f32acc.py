@@ -39,6 +39,11 @@ def test_gemm_f32_matches_f64(dev, M, K, N, act, res):
     lib_err = _rel(F.linear(x, w, bias) if act is None and not res else outs[0], ref)
     err = _rel(outs[0], ref)
     assert err < 4e-6, (err, lib_err)
+    # the one-launch form (both planes at one scale, three MFMAs per k-step into one accumulator): same bound
+    packs1, tile1, n1, sw = ops.gemm_pack_weight_f16(w, one_scale=True)
+    fused = [ops.gemm_f32_fused(x, packs1, N, sw, bias=bias, act=act, residual=r) for _ in range(2)]
+    assert torch.equal(fused[0], fused[1]) and tile1 == 128 and n1 == N
+    assert _rel(fused[0], ref) < 4e-6, _rel(fused[0], ref)
     assert lib().xm3d_check_flag() == 0
 
 
@@ -63,3 +68,24 @@ def test_conv_gemm_f32_matches_f64(dev, B, cin, H, W, cout, k, stride, pad):
     outs = [ops.conv_gemm_f32(x, packs, tile, n32, cout, k, stride, pad, bias=bpad, residual=res) for _ in range(2)]
     assert torch.equal(outs[0], outs[1]) and outs[0].dtype == torch.float32 and outs[0].shape == ref.shape
     assert _rel(outs[0], ref) < 4e-6
+    packs1, _, n1, sw = ops.gemm_pack_weight_f16(w, one_scale=True)
+    fused = [ops.conv_gemm_f32_fused(x, packs1, n1, sw, cout, k, stride, pad, bias=bpad, residual=res) for _ in range(2)]
+    assert torch.equal(fused[0], fused[1]) and fused[0].shape == ref.shape
+    assert _rel(fused[0], ref) < 4e-6, _rel(fused[0], ref)
+
+
+def test_one_scale_split_flags_operands_beyond_the_half_range(dev):
+    from xmask3d_amd import ops
+    from xmask3d_amd._lib import lib
+
+    w = torch.randn(64, 128, device=dev) / 11
+    packs, _, n, sw = ops.gemm_pack_weight_f16(w, one_scale=True)
+    x = torch.randn(300, 128, device=dev)
+    assert lib().xm3d_check_flag() == 0
+    ops.gemm_f32_fused(x, packs, n, sw)
+    torch.cuda.synchronize()
+    assert lib().xm3d_check_flag() == 0
+    x[7, 3] = 5000.0  # * 16 > 65504
+    ops.gemm_f32_fused(x, packs, n, sw)
+    torch.cuda.synchronize()
+    assert lib().xm3d_check_flag() != 0 and lib().xm3d_check_flag() == 0

@@ -468,7 +468,8 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3_f32acc(const ConvArgs a)
 // f16 (scale_hi > 0): hi = half(y * scale_hi), lo = half((y - hi / scale_hi) * scale_hi * 2^11): y = hi / s + lo / (s 2^11) to 2^-22 |y|; both terms
 // live at the magnitude of y * s, so neither loses bits to the half's narrow exponent range; values beyond 65504 / s set the range flag
 __global__ void k_split_nhwc(const float* __restrict__ x, const float* __restrict__ affine, int act, int64_t n8, int C, int64_t hw,
-                             __bf16* __restrict__ hi, __bf16* __restrict__ lo, __bf16* __restrict__ lo2, float scale_hi, int* __restrict__ flag) {
+                             __bf16* __restrict__ hi, __bf16* __restrict__ lo, __bf16* __restrict__ lo2, float scale_hi, float lo_mul,
+                             int* __restrict__ flag) {
     const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i >= n8) return;
     const int c8 = C / 8;
@@ -488,7 +489,7 @@ __global__ void k_split_nhwc(const float* __restrict__ x, const float* __restric
     }
     if (scale_hi > 0.f) {
         cv_f16x8 h8, l8;
-        const float inv = 1.f / scale_hi, sl = scale_hi * 2048.f;  // powers of two: exact
+        const float inv = 1.f / scale_hi, sl = scale_hi * lo_mul;  // powers of two: exact (lo_mul 2048: the scaled small term; 1: at hi's scale)
         bool bad = false;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
@@ -732,7 +733,7 @@ extern "C" int xm3d_conv3x3_nhwc(const void* x, int64_t B, int H, int W, int cin
 //      <= 2^-16 |x w| each), f32 accumulation across the passes in the f32 output tensor.
 static int split_nhwc_impl(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
                            const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, void* hi, void* lo,
-                           void* lo2, float scale_hi, void* ws, void* stream) {
+                           void* lo2, float scale_hi, float lo_mul, void* ws, void* stream) {
     XM3D_REQUIRE(x && hi && lo, "split_bf16_nhwc: null pointer");
     XM3D_REQUIRE(B > 0 && HW > 0 && C > 0 && C % 8 == 0, "split_bf16_nhwc: C %d must be a multiple of 8", C);
     XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(hi) | reinterpret_cast<uintptr_t>(lo)) & 15) == 0,
@@ -751,7 +752,7 @@ static int split_nhwc_impl(const float* x, int64_t B, int64_t HW, int32_t C, con
     }
     const int64_t n8 = B * HW * (C / 8);
     hipLaunchKernelGGL(k_split_nhwc, dim3(unsigned((n8 + 255) / 256)), dim3(256), 0, s, x, affine, act, n8, C, HW, static_cast<__bf16*>(hi),
-                       static_cast<__bf16*>(lo), static_cast<__bf16*>(lo2), scale_hi, device_flag());
+                       static_cast<__bf16*>(lo), static_cast<__bf16*>(lo2), scale_hi, lo_mul, device_flag());
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
@@ -759,7 +760,7 @@ static int split_nhwc_impl(const float* x, int64_t B, int64_t HW, int32_t C, con
 extern "C" int xm3d_split_bf16_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
                                     const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, void* hi, void* lo,
                                     void* lo2, void* ws, void* stream) {
-    return split_nhwc_impl(x, B, HW, C, gn_stats, gamma, beta, in_shift, in_shift_bstride, eps, groups, act, hi, lo, lo2, 0.f, ws, stream);
+    return split_nhwc_impl(x, B, HW, C, gn_stats, gamma, beta, in_shift, in_shift_bstride, eps, groups, act, hi, lo, lo2, 0.f, 0.f, ws, stream);
 }
 
 // the two-term split in IEEE halves: y = hi / scale_hi + lo / (scale_hi * 2048), |y - (..)| <= 2^-22 |y| (see k_split_nhwc); scale_hi a power
@@ -768,7 +769,17 @@ extern "C" int xm3d_split_f16_nhwc(const float* x, int64_t B, int64_t HW, int32_
                                    const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, float scale_hi, void* hi,
                                    void* lo, void* ws, void* stream) {
     XM3D_REQUIRE(scale_hi > 0.f, "split_f16_nhwc: scale_hi must be positive");
-    return split_nhwc_impl(x, B, HW, C, gn_stats, gamma, beta, in_shift, in_shift_bstride, eps, groups, act, hi, lo, nullptr, scale_hi, ws, stream);
+    return split_nhwc_impl(x, B, HW, C, gn_stats, gamma, beta, in_shift, in_shift_bstride, eps, groups, act, hi, lo, nullptr, scale_hi, 2048.f, ws, stream);
+}
+
+// ... with both terms at ONE scale: y * scale_hi = hi + lo (lo = half(y scale_hi - hi), not times 2^11) - the operand form of the one-launch
+// f32-accurate GEMM (xm3d_gemm_f32), whose three products share one accumulator.  lo is a normal half while |y| scale_hi >= 2^-3; smaller
+// values keep an absolute precision of 2^-24 / scale_hi.  Range: |y| scale_hi <= 65504 (beyond: the sticky range flag).
+extern "C" int xm3d_split_f16t_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const double* gn_stats, const float* gamma, const float* beta,
+                                    const float* in_shift, int32_t in_shift_bstride, float eps, int32_t groups, int32_t act, float scale_hi, void* hi,
+                                    void* lo, void* ws, void* stream) {
+    XM3D_REQUIRE(scale_hi > 0.f, "split_f16t_nhwc: scale_hi must be positive");
+    return split_nhwc_impl(x, B, HW, C, gn_stats, gamma, beta, in_shift, in_shift_bstride, eps, groups, act, hi, lo, nullptr, scale_hi, 1.f, ws, stream);
 }
 
 // out (f32) = conv3x3(x bf16, w bf16 packed) + bias + residual (f32; may be `out` itself: accumulate in place)

@@ -50,6 +50,8 @@ struct GemmArgs {
     const float* bias;       // (N) or null; GEGLU: (2 N_out), value half first
     const __bf16* residual;  // (M, N_out), row stride ldr, or null (GF_OUT32: f32)
     __bf16* out;             // (M, N_out), row stride ldo (GF_OUT32: f32; split-K: slab blockIdx.y at + blockIdx.y * M * ldo)
+    const __bf16* x2;        // GF_SPLIT3: the small-term plane of x (same layout as x)
+    const __bf16* wp2;       // GF_SPLIT3: the packed small-term image of W
     const float* accin;      // GF_OUT32: (M, N_out) f32, row stride ldo, added BEFORE the activation (accumulating passes), or null
     float alpha;             // GF_OUT32: the product is scaled by alpha (the power-of-two scale of a split term pair) before anything is added
     int M, K, N;             // N = rows of W (GEGLU: 2 N_out)
@@ -64,7 +66,11 @@ struct GemmArgs {
 // strided / small-map / 1x1 convolutions that conv.hip's 32-pixel-wide halo tiles do not take.  GF_OUT32: f32 output (accumulating
 // passes of the f32-accurate GEMM, partial slabs of the deterministic split-K).  GF_F16: operands are IEEE half (v_mfma_f32_32x32x16_f16):
 // the two-term split of an f32 operand in halves carries 22 mantissa bits (bf16: 16)
-enum { GF_CONV = 1, GF_OUT32 = 2, GF_F16 = 4 };
+// GF_SPLIT3 (with GF_F16 | GF_OUT32): the whole f32-accurate product in ONE launch - both planes of x (x, x2) staged, both weight images
+// (wp, wp2) streamed, three MFMAs per k-step into ONE accumulator: x_hi w_lo + x_lo w_hi + x_hi w_hi.  Needs the small terms at their TRUE
+// scale (lo = half(x s - hi), not times 2^11): fine while |x s| >= 2^-3 keeps lo a normal half - smaller |x| lose only absolute precision
+// (2^-24 / s), which is invisible next to 1e-6 of max|out|.  A third of the token / output traffic of the three accumulating passes.
+enum { GF_CONV = 1, GF_OUT32 = 2, GF_F16 = 4, GF_SPLIT3 = 8 };
 typedef _Float16 gm_f16x8 __attribute__((ext_vector_type(8)));
 
 // GELU(x) = x/2 (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, two hardware transcendentals)
@@ -83,8 +89,10 @@ __device__ __forceinline__ float gm_gelu(float x) {
 template <int CT, int ACT, int KC, int NW, int FL>
 __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     static_assert(NW == 8 || (NW == 4 && CT == 128), "geometries");
-    constexpr bool CONV = (FL & GF_CONV) != 0, OUT32 = (FL & GF_OUT32) != 0, F16 = (FL & GF_F16) != 0;
+    constexpr bool CONV = (FL & GF_CONV) != 0, OUT32 = (FL & GF_OUT32) != 0, F16 = (FL & GF_F16) != 0, SP3 = (FL & GF_SPLIT3) != 0;
     static_assert(!OUT32 || ACT != GM_ACT_GEGLU, "GEGLU has no f32-output form");
+    static_assert(!SP3 || (F16 && OUT32 && CT == 128 && KC == 64), "the one-launch split form: halves, f32 out, 128-column tiles, 64-channel chunks");
+    constexpr int NPLN = SP3 ? 2 : 1;      // operand planes staged per buffer
     constexpr int MT = NW * 32;            // token rows per workgroup
     constexpr int NTH = NW * 64;
     constexpr int NT = CT == 256 ? 8 : 4;  // 32-token tiles per wave
@@ -93,7 +101,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     constexpr int PSTR = KC * 2 + 16;      // bytes per staged row (144 / 272: the 32-row fragment reads stay bank-conflict free)
     constexpr int ASZ = MT * PSTR;         // bytes per LDS buffer
     constexpr int RPR = NTH / (KC / 8);    // rows staged per round
-    constexpr int D = (CT == 256 && KC == 128) ? 4 : GM_D;  // weight ring depth in k-steps (register budget: 128 accumulators + 32 pieces there)
+    constexpr int D = ((CT == 256 && KC == 128) || SP3) ? 4 : GM_D;  // weight ring depth in k-steps (register budget: 128 accumulators + 32 pieces there; two rings with SP3)
     extern __shared__ __attribute__((aligned(16))) char smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -119,9 +127,13 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
 
     // ---- weight stream of this wave: 1 KiB (64 lanes x 16 bytes = one A fragment) per k-step, contiguous
     const char* const wstream = reinterpret_cast<const char*>(a.wp) + ((int64_t(ct) * (CT / 32) + wb) * (a.K / 16) + int64_t(cfirst) * KS) * 1024 + lane * 16;
-    gm_bf16x8 wr[D];
+    const char* const wstream2 = SP3 ? reinterpret_cast<const char*>(a.wp2) + (wstream - reinterpret_cast<const char*>(a.wp)) : nullptr;
+    gm_bf16x8 wr[D], wr2[SP3 ? D : 1];
 #pragma unroll
-    for (int i = 0; i < D; ++i) wr[i] = *reinterpret_cast<const gm_bf16x8*>(wstream + int64_t(i < nk ? i : nk - 1) * 1024);
+    for (int i = 0; i < D; ++i) {
+        wr[i] = *reinterpret_cast<const gm_bf16x8*>(wstream + int64_t(i < nk ? i : nk - 1) * 1024);
+        if constexpr (SP3) wr2[i] = *reinterpret_cast<const gm_bf16x8*>(wstream2 + int64_t(i < nk ? i : nk - 1) * 1024);
+    }
 
     // ---- token staging: thread owns the 16-byte piece (row prow + RPR r, channels 8 kc .. 8 kc + 7) of every chunk, r = 0 .. KS - 1.
     // Rows past M read row M - 1 (their results are never stored).  ONE register per piece: piece r of chunk c + 1 is written to LDS
@@ -149,7 +161,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
         }
     }
     char* const a_wr = smem + prow * PSTR + kc * 16;  // + r * RPR * PSTR + buffer
-    gm_u32x4 raw[KS];
+    gm_u32x4 raw[KS], raw2[SP3 ? KS : 1];
     // GF_CONV: chunk -> (filter tap, channel slice), walked incrementally (wave-uniform): `ld` is the chunk being requested, `wr_need`
     // the validity bits of the chunk whose pieces are being written to LDS (requested one chunk earlier)
     const int cpt = CONV ? a.Cin / KC : 1;  // chunks per tap
@@ -177,16 +189,23 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     };
     // request piece r of the chunk `ld` points at (plain: of local chunk c, clamped to the slice's last)
     auto a_load = [&](int r, int c) __attribute__((always_inline)) {
+        int off;
         if constexpr (CONV) {
             const bool ok = (vmask[r] & ld.need) == ld.need;
-            raw[r] = *reinterpret_cast<const gm_u32x4*>(a.x + (ok ? aoff[r] + ld.off : kc * 8));
+            off = ok ? aoff[r] + ld.off : kc * 8;
         } else {
-            raw[r] = *reinterpret_cast<const gm_u32x4*>(a.x + aoff[r] + (cfirst + (c < nch ? c : nch - 1)) * KC);
+            off = aoff[r] + (cfirst + (c < nch ? c : nch - 1)) * KC;
         }
+        raw[r] = *reinterpret_cast<const gm_u32x4*>(a.x + off);
+        if constexpr (SP3) raw2[r] = *reinterpret_cast<const gm_u32x4*>(a.x2 + off);
     };
     auto a_piece = [&](int r) __attribute__((always_inline)) -> gm_u32x4 {  // zero padding: a piece under a tap outside the image
         if constexpr (CONV) return (vmask[r] & wr_need) == wr_need ? raw[r] : gm_u32x4{0u, 0u, 0u, 0u};
         else return raw[r];
+    };
+    auto a_piece2 = [&](int r) __attribute__((always_inline)) -> gm_u32x4 {
+        if constexpr (CONV) return (vmask[r] & wr_need) == wr_need ? raw2[SP3 ? r : 0] : gm_u32x4{0u, 0u, 0u, 0u};
+        else return raw2[SP3 ? r : 0];
     };
 
     // tokens as B operand: row (nbase + n) * 32 + l31 of the tile, 16-byte granule 2 ks + h
@@ -204,7 +223,10 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     for (int r = 0; r < KS; ++r) a_load(r, 0);
     wr_need = ld.need;
 #pragma unroll
-    for (int r = 0; r < KS; ++r) *reinterpret_cast<gm_u32x4*>(a_wr + r * RPR * PSTR) = a_piece(r);
+    for (int r = 0; r < KS; ++r) {
+        *reinterpret_cast<gm_u32x4*>(a_wr + r * RPR * PSTR) = a_piece(r);
+        if constexpr (SP3) *reinterpret_cast<gm_u32x4*>(a_wr + ASZ + r * RPR * PSTR) = a_piece2(r);
+    }
     if constexpr (CONV) {
         if (nch > 1) tap_next(ld);
     }
@@ -217,18 +239,21 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     auto chunk = [&](int c, auto par_tag, auto act_tag) __attribute__((always_inline)) {
         constexpr int P = decltype(par_tag)::value;
         constexpr bool ACTV = decltype(act_tag)::value;  // a wave past N only stages (one branch per chunk, straight-line bodies)
-        const char* const xl = xbase + P * ASZ;
-        char* const anext = a_wr + (1 - P) * ASZ;
+        const char* const xl = xbase + P * NPLN * ASZ;  // buffer P: plane 0 (leading terms), plane 1 at + ASZ (GF_SPLIT3)
+        char* const anext = a_wr + (1 - P) * NPLN * ASZ;
         if constexpr (CONV) {  // the pieces in flight belong to chunk c + 1 (written in this chunk); requests go to chunk c + 2
             wr_need = ld.need;
             if (c + 2 < nch) tap_next(ld);
         }
-        gm_bf16x8 xf[2][4];
+        gm_bf16x8 xf[2][4], xf2[SP3 ? 2 : 1][4];
         constexpr int XS = KS * NG;  // x-sets (4 token tiles each) per chunk
         auto x_load = [&](int xs, int s) __attribute__((always_inline)) {
             const int ks = xs / NG, half = xs % NG;
 #pragma unroll
-            for (int n = 0; n < 4; ++n) xf[s][n] = *reinterpret_cast<const gm_bf16x8*>(xl + (half * 4 + n) * 32 * PSTR + ks * 32);
+            for (int n = 0; n < 4; ++n) {
+                xf[s][n] = *reinterpret_cast<const gm_bf16x8*>(xl + (half * 4 + n) * 32 * PSTR + ks * 32);
+                if constexpr (SP3) xf2[s][n] = *reinterpret_cast<const gm_bf16x8*>(xl + ASZ + (half * 4 + n) * 32 * PSTR + ks * 32);
+            }
         };
         if (ACTV) x_load(0, 0);
 #pragma unroll
@@ -240,11 +265,18 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
             __builtin_amdgcn_sched_barrier(0);
             if (half == 0) {
                 *reinterpret_cast<gm_u32x4*>(anext + ks * RPR * PSTR) = a_piece(ks);
+                if constexpr (SP3) *reinterpret_cast<gm_u32x4*>(anext + ASZ + ks * RPR * PSTR) = a_piece2(ks);
                 a_load(ks, c + 2);
             }
             if (ACTV) {
 #pragma unroll
                 for (int n = 0; n < 4; ++n) {
+                    if constexpr (SP3) {  // small products first, the leading one last
+                        acc[half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gm_f16x8, wr2[slot]), __builtin_bit_cast(gm_f16x8, xf[g & 1][n]),
+                                                                                   acc[half * 4 + n], 0, 0, 0);
+                        acc[half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gm_f16x8, wr[slot]), __builtin_bit_cast(gm_f16x8, xf2[g & 1][n]),
+                                                                                   acc[half * 4 + n], 0, 0, 0);
+                    }
                     if constexpr (F16)
                         acc[half * 4 + n] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(gm_f16x8, wr[slot]), __builtin_bit_cast(gm_f16x8, xf[g & 1][n]),
                                                                                    acc[half * 4 + n], 0, 0, 0);
@@ -254,6 +286,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
                     __builtin_amdgcn_sched_barrier(0);
                     const int jn = c * KS + ks + D;
                     wr[slot] = *reinterpret_cast<const gm_bf16x8*>(wstream + int64_t(jn < nk ? jn : nk - 1) * 1024);
+                    if constexpr (SP3) wr2[slot] = *reinterpret_cast<const gm_bf16x8*>(wstream2 + int64_t(jn < nk ? jn : nk - 1) * 1024);
                 }
             }
         }
@@ -453,7 +486,7 @@ __global__ void k_gemm_splitk_finish(const float* __restrict__ slab, int ksplit,
 template <int CT, int ACT, int KC, int NW, int FL>
 static int launch_gemm_kc(const GemmArgs& a0, int ksplit, hipStream_t s) {
     constexpr int MT = NW * 32;
-    constexpr int LDS = 2 * MT * (KC * 2 + 16);
+    constexpr int LDS = 2 * ((FL & GF_SPLIT3) ? 2 : 1) * MT * (KC * 2 + 16);
     static DeviceOnce configured;  // the attribute is per device
     if (configured.first()) {
         XM3D_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm<CT, ACT, KC, NW, FL>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS));
@@ -472,11 +505,16 @@ static int launch_gemm_kc(const GemmArgs& a0, int ksplit, hipStream_t s) {
 // chunks.  waves: 8 / 4 (4: CT = 128 only)
 template <int CT, int ACT, int FL>
 static int launch_gemm(const GemmArgs& a, int waves, int ksplit, hipStream_t s) {
-    const bool kc128 = ((FL & GF_CONV) ? a.Cin : a.K) % 128 == 0;
-    if constexpr (CT == 128) {
-        if (waves == 4) return kc128 ? launch_gemm_kc<CT, ACT, 128, 4, FL>(a, ksplit, s) : launch_gemm_kc<CT, ACT, 64, 4, FL>(a, ksplit, s);
+    if constexpr ((FL & GF_SPLIT3) != 0) {  // 128-column tiles, 64-channel chunks only
+        if constexpr (CT == 128) return waves == 4 ? launch_gemm_kc<128, ACT, 64, 4, FL>(a, ksplit, s) : launch_gemm_kc<128, ACT, 64, 8, FL>(a, ksplit, s);
+        else return XM3D_EINVAL;
+    } else {
+        const bool kc128 = ((FL & GF_CONV) ? a.Cin : a.K) % 128 == 0;
+        if constexpr (CT == 128) {
+            if (waves == 4) return kc128 ? launch_gemm_kc<CT, ACT, 128, 4, FL>(a, ksplit, s) : launch_gemm_kc<CT, ACT, 64, 4, FL>(a, ksplit, s);
+        }
+        return kc128 ? launch_gemm_kc<CT, ACT, 128, 8, FL>(a, ksplit, s) : launch_gemm_kc<CT, ACT, 64, 8, FL>(a, ksplit, s);
     }
-    return kc128 ? launch_gemm_kc<CT, ACT, 128, 8, FL>(a, ksplit, s) : launch_gemm_kc<CT, ACT, 64, 8, FL>(a, ksplit, s);
 }
 
 template <int CT>
@@ -562,6 +600,7 @@ extern "C" int xm3d_gemm_bf16(const void* x, int64_t M, int K, int64_t ldx, cons
     a.residual = static_cast<const __bf16*>(residual);
     a.out = static_cast<__bf16*>(out);
     a.accin = nullptr;
+    a.x2 = a.wp2 = nullptr;
     a.alpha = 1.f;
     a.M = int(M), a.K = K, a.N = N;
     a.ldx = int(ldx), a.ldr = int(ldr), a.ldo = int(ldo);
@@ -614,6 +653,7 @@ extern "C" int xm3d_conv_gemm_bf16(const void* x, int64_t B, int32_t Hin, int32_
     a.x = static_cast<const __bf16*>(x);
     a.wp = static_cast<const __bf16*>(wpacked);
     a.accin = nullptr;
+    a.x2 = a.wp2 = nullptr;
     a.alpha = 1.f;
     a.M = int(M), a.K = ksize * ksize * Cin, a.N = N;
     a.ldx = 0, a.ldr = N, a.ldo = N;
@@ -647,11 +687,14 @@ extern "C" int xm3d_conv_gemm_bf16(const void* x, int64_t B, int32_t Hin, int32_
 // ONE pass: out (f32) = act(alpha * (x_term @ W_term^T) + bias + accin) + residual.  The caller runs the three term pairs with
 // accin = out (xmask3d_amd.ops.gemm_f32 / conv_gemm_f32).  x: (M, K) halves, row stride ldx (conv = 0), or the channels-last image
 // (B, Hin, Win, Cin) in halves (conv = 1: geometry as xm3d_conv_gemm_bf16, M = B * Ho * Wo, no split-K).
-extern "C" int xm3d_gemm_f32acc(const void* x, int64_t M, int32_t K, int64_t ldx, const void* wpacked, int32_t N, int32_t col_tile, const float* bias,
-                                int32_t act, float alpha, const float* accin, const float* residual, int64_t ldr, float* out, int64_t ldo, int32_t waves,
-                                int32_t conv, int64_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t,
-                                int32_t pad_l, int32_t Ho, int32_t Wo, void* stream) {
+static int gemm_f32acc_impl(const void* x, const void* x_lo, int64_t M, int32_t K, int64_t ldx, const void* wpacked, const void* wpacked_lo, int32_t N,
+                           int32_t col_tile, const float* bias, int32_t act, float alpha, const float* accin, const float* residual, int64_t ldr, float* out,
+                           int64_t ldo, int32_t waves, int32_t conv, int64_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t ksize, int32_t stride,
+                           int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, void* stream) {
     XM3D_REQUIRE(x && wpacked && out, "gemm_f32acc: null pointer");
+    const bool fused = x_lo != nullptr;
+    XM3D_REQUIRE(!fused || (wpacked_lo && !accin && ((reinterpret_cast<uintptr_t>(x_lo) | reinterpret_cast<uintptr_t>(wpacked_lo)) & 15) == 0),
+                 "gemm_f32: the one-launch form needs both planes of x and both weight images (16-byte aligned), and takes no accin");
     XM3D_REQUIRE(col_tile == 128 || col_tile == 256, "gemm_f32acc: column tile %d unsupported", col_tile);
     XM3D_REQUIRE(N > 0 && N % 32 == 0, "gemm_f32acc: N %d is not a multiple of 32", N);
     XM3D_REQUIRE(act >= 0 && act <= 2, "gemm_f32acc: epilogue %d unsupported (none, GELU, QuickGELU)", act);
@@ -676,17 +719,27 @@ extern "C" int xm3d_gemm_f32acc(const void* x, int64_t M, int32_t K, int64_t ldx
     a.residual = reinterpret_cast<const __bf16*>(residual);
     a.out = reinterpret_cast<__bf16*>(out);
     a.accin = accin;
+    a.x2 = static_cast<const __bf16*>(x_lo);
+    a.wp2 = static_cast<const __bf16*>(wpacked_lo);
     a.alpha = alpha;
     a.M = int(M), a.K = K, a.N = N;
     a.ldx = int(ldx), a.ldr = int(ldr), a.ldo = int(ldo);
     a.Hin = Hin, a.Win = Win, a.Cin = Cin, a.Ho = Ho, a.Wo = Wo, a.stride = stride, a.pad_t = pad_t, a.pad_l = pad_l, a.ksz = ksize;
     int tile = col_tile;
+    if (fused) tile = 128;
     if (tile == 256 && ((M + 255) / 256) * ((N + 255) / 256) < 200) tile = 128;
     XM3D_REQUIRE(waves == 0 || waves == 8 || (waves == 4 && tile == 128), "gemm_f32acc: waves must be 0 (choose), 8, or 4 with column tile 128");
     if (waves == 0) waves = tile == 128 ? xm3d_gemm_default_waves(M, N, 128) : 8;
     a.nct = (N + tile - 1) / tile;
     hipStream_t s = as_stream(stream);
     constexpr int FG = GF_F16 | GF_OUT32, FC = GF_F16 | GF_OUT32 | GF_CONV;
+    if (fused) {
+        constexpr int SG = FG | GF_SPLIT3, SC = FC | GF_SPLIT3;
+        if (conv) return launch_gemm<128, GM_ACT_NONE, SC>(a, waves, 1, s);
+        if (act == GM_ACT_GELU) return launch_gemm<128, GM_ACT_GELU, SG>(a, waves, 1, s);
+        if (act == GM_ACT_QUICK_GELU) return launch_gemm<128, GM_ACT_QUICK_GELU, SG>(a, waves, 1, s);
+        return launch_gemm<128, GM_ACT_NONE, SG>(a, waves, 1, s);
+    }
     if (conv) return tile == 256 ? launch_gemm<256, GM_ACT_NONE, FC>(a, waves, 1, s) : launch_gemm<128, GM_ACT_NONE, FC>(a, waves, 1, s);
     if (tile == 256) {
         if (act == GM_ACT_GELU) return launch_gemm<256, GM_ACT_GELU, FG>(a, waves, 1, s);
@@ -696,4 +749,25 @@ extern "C" int xm3d_gemm_f32acc(const void* x, int64_t M, int32_t K, int64_t ldx
     if (act == GM_ACT_GELU) return launch_gemm<128, GM_ACT_GELU, FG>(a, waves, 1, s);
     if (act == GM_ACT_QUICK_GELU) return launch_gemm<128, GM_ACT_QUICK_GELU, FG>(a, waves, 1, s);
     return launch_gemm<128, GM_ACT_NONE, FG>(a, waves, 1, s);
+}
+
+extern "C" int xm3d_gemm_f32acc(const void* x, int64_t M, int32_t K, int64_t ldx, const void* wpacked, int32_t N, int32_t col_tile, const float* bias,
+                                int32_t act, float alpha, const float* accin, const float* residual, int64_t ldr, float* out, int64_t ldo, int32_t waves,
+                                int32_t conv, int64_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t,
+                                int32_t pad_l, int32_t Ho, int32_t Wo, void* stream) {
+    return gemm_f32acc_impl(x, nullptr, M, K, ldx, wpacked, nullptr, N, col_tile, bias, act, alpha, accin, residual, ldr, out, ldo, waves, conv, B, Hin, Win, Cin,
+                            ksize, stride, pad_t, pad_l, Ho, Wo, stream);
+}
+
+// The whole f32-accurate product in ONE launch (GF_SPLIT3): x_hi / x_lo = the two half planes of x AT ONE SCALE (x s = hi + lo: the split with
+// lo_mul = 1), wp_hi / wp_lo the packed images of the two half terms of W t; alpha = 1 / (s t).
+//     out (f32) = act( alpha * (x_hi W_hi^T + x_hi W_lo^T + x_lo W_hi^T) + bias ) + residual
+// Same shapes / convolution form as xm3d_gemm_f32acc; 128-column tiles.
+extern "C" int xm3d_gemm_f32(const void* x_hi, const void* x_lo, int64_t M, int32_t K, int64_t ldx, const void* wp_hi, const void* wp_lo, int32_t N,
+                             const float* bias, int32_t act, float alpha, const float* residual, int64_t ldr, float* out, int64_t ldo, int32_t waves, int32_t conv,
+                             int64_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho,
+                             int32_t Wo, void* stream) {
+    XM3D_REQUIRE(x_lo && wp_lo, "gemm_f32: null pointer");
+    return gemm_f32acc_impl(x_hi, x_lo, M, K, ldx, wp_hi, wp_lo, N, 128, bias, act, alpha, nullptr, residual, ldr, out, ldo, waves, conv, B, Hin, Win, Cin, ksize,
+                            stride, pad_t, pad_l, Ho, Wo, stream);
 }

@@ -7,6 +7,7 @@ fallbacks: tensors must live on a ROCm device.
 from __future__ import annotations
 
 import ctypes
+import math
 
 import numpy as np
 import torch
@@ -553,11 +554,11 @@ F16_LO_SCALE = 2048.0   # the second term of a split in halves is stored times 2
 F16_X_SCALE = 2.0 ** -6  # activations are split as hi = half(x * 2^-6): |x| up to 4.2e6 before the half overflows (flagged by the kernel)
 
 
-def split_f16(t, scale_hi=1.0):
-    """f32 tensor -> (hi, lo) halves with t = hi / scale_hi + lo / (scale_hi * 2048) to 2^-22 |t| (torch ops; weights, once)"""
+def split_f16(t, scale_hi=1.0, lo_mul=F16_LO_SCALE):
+    """f32 tensor -> (hi, lo) halves with t = hi / scale_hi + lo / (scale_hi * lo_mul) to 2^-22 |t| (torch ops; weights, once)"""
     t = t.detach().float()
     hi = (t * scale_hi).to(torch.float16)
-    lo = ((t - hi.float() / scale_hi) * (scale_hi * F16_LO_SCALE)).to(torch.float16)
+    lo = ((t - hi.float() / scale_hi) * (scale_hi * lo_mul)).to(torch.float16)
     return hi, lo
 
 
@@ -746,9 +747,14 @@ def conv_gemm(x, packed, tile, n32, cout, ksize, stride=1, padding=(0, 0, 0, 0),
 
 
 # ---- f32-accurate GEMM / implicit-GEMM convolution: three matrix-core passes over operands split in IEEE halves (xm3d_gemm_f32acc)
-def gemm_pack_weight_f16(weight):
+F16T_X_SCALE = 16.0  # one-launch form: activations split as x * 16 = hi + lo (both halves at one scale): |x| up to 4094, lo normal for |x| >= 2^-7
+
+
+def gemm_pack_weight_f16(weight, one_scale=False):
     """f32 Linear / Conv2d weight (N, K) or (N, cin, k, k) -> ([packed hi, packed lo], column tile, padded N): the two-term split in
-    halves (split_f16); convolution weights go in (ky, kx, cin) order, N is padded with zero rows to a multiple of 32"""
+    halves (split_f16); convolution weights go in (ky, kx, cin) order, N is padded with zero rows to a multiple of 32.
+    one_scale: the operand form of the one-launch GEMM (gemm_f32_fused): W t = hi + lo with t the largest power of two that keeps
+    |W| t <= 32768 -> ([packed hi, packed lo], 128, padded N, t)"""
     w = weight.detach().float()
     if w.dim() == 4:
         w = w.permute(0, 2, 3, 1)
@@ -757,11 +763,16 @@ def gemm_pack_weight_f16(weight):
     if n32 != w.shape[0]:
         w = torch.cat([w, torch.zeros(n32 - w.shape[0], w.shape[1], dtype=w.dtype, device=w.device)])
     packs, tile = [], None
-    for t in split_f16(w):
+    sw = 1.0
+    if one_scale:
+        amax = float(w.abs().max()) if w.numel() else 0.0
+        sw = 2.0 ** math.floor(math.log2(32768.0 / amax)) if amax > 0 else 1.0
+        sw = min(max(sw, 2.0 ** -14), 2.0 ** 24)
+    for t in split_f16(w, sw, 1.0 if one_scale else F16_LO_SCALE):
         # the packer moves 16-bit words (its bf16 -> f32 -> bf16 round trip is the identity on them)
         p_, tile = gemm_pack_weight(t.contiguous().view(torch.bfloat16))
         packs.append(p_)
-    return packs, tile, n32
+    return (packs, 128, n32, sw) if one_scale else (packs, tile, n32)
 
 
 def _split_rows_f16(x2):
@@ -771,6 +782,65 @@ def _split_rows_f16(x2):
     check(lib().xm3d_split_f16_nhwc(_ptr(x2), 1, m, k, None, None, None, None, 0, 0.0, 0, 0, F16_X_SCALE, _ptr(hi), _ptr(lo), None, _stream()),
           "xm3d_split_f16_nhwc")
     return hi, lo
+
+
+def _split_rows_f16t(x2):
+    """(M, K) contiguous f32 -> (hi, lo) halves with x * F16T_X_SCALE = hi + lo (one pass)"""
+    m, k = x2.shape
+    hi, lo = torch.empty((m, k), dtype=torch.float16, device=x2.device), torch.empty((m, k), dtype=torch.float16, device=x2.device)
+    check(lib().xm3d_split_f16t_nhwc(_ptr(x2), 1, m, k, None, None, None, None, 0, 0.0, 0, 0, F16T_X_SCALE, _ptr(hi), _ptr(lo), None, _stream()),
+          "xm3d_split_f16t_nhwc")
+    return hi, lo
+
+
+def gemm_f32_fused(x, packs, n, sw, bias=None, act=None, residual=None):
+    """gemm_f32 in ONE launch (xm3d_gemm_f32): packs, sw = gemm_pack_weight_f16(W, one_scale=True)[0, 3].  A third of the traffic of the three
+    accumulating passes; activations beyond |x| = 4094 raise the sticky range flag."""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.shape[-1] % 64 == 0):
+        raise TypeError(f"gemm_f32_fused: f32 device tensor with K % 64 == 0 required, got {tuple(x.shape)} {x.dtype}")
+    k = x.shape[-1]
+    x2 = x.reshape(-1, k)
+    if not x2.is_contiguous():
+        x2 = x2.contiguous()
+    m = x2.shape[0]
+    hi, lo = _split_rows_f16t(x2)
+    out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
+    ldr = 0
+    if residual is not None:
+        if residual.dtype != torch.float32 or residual.shape != out.shape or not residual.is_contiguous():
+            raise TypeError("gemm_f32_fused: residual must be a contiguous f32 tensor of the output's shape")
+        ldr = n
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != n):
+        raise TypeError("gemm_f32_fused: bias must be a contiguous f32 (n,) tensor")
+    check(lib().xm3d_gemm_f32(_ptr(hi), _ptr(lo), m, k, k, _ptr(packs[0]), _ptr(packs[1]), n, _ptr(bias), GEMM_ACTS[act], 1.0 / (F16T_X_SCALE * sw),
+                              _ptr(residual), ldr, _ptr(out), n, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, _stream()), "xm3d_gemm_f32")
+    return out
+
+
+def conv_gemm_f32_fused(x, packs, n32, sw, cout, ksize, stride=1, padding=(0, 0, 0, 0), bias=None, residual=None):
+    """conv_gemm_f32 in ONE launch (xm3d_gemm_f32, convolution form); packs, n32, sw from gemm_pack_weight_f16(W, one_scale=True)"""
+    if not (is_nhwc(x) and x.dtype == torch.float32 and x.shape[1] % 64 == 0):
+        raise TypeError(f"conv_gemm_f32_fused: channels-last f32 device tensor with cin % 64 == 0 required, got {tuple(x.shape)} {x.dtype}")
+    B, cin, H, W = x.shape
+    pt, pl, pb, pr = (int(p) for p in padding)
+    Ho, Wo = (H + pt + pb - ksize) // stride + 1, (W + pl + pr - ksize) // stride + 1
+    hi = torch.empty((B, cin, H, W), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+    lo = torch.empty_like(hi)
+    check(lib().xm3d_split_f16t_nhwc(_ptr(x), B, H * W, cin, None, None, None, None, 0, 0.0, 0, 0, F16T_X_SCALE, _ptr(hi), _ptr(lo), None, _stream()),
+          "xm3d_split_f16t_nhwc")
+    out = torch.empty((B, Ho, Wo, n32), dtype=torch.float32, device=x.device)
+    ldr = 0
+    if residual is not None:
+        if n32 != cout or residual.dtype != torch.float32 or tuple(residual.shape) != (B, cout, Ho, Wo) or not is_nhwc(residual):
+            raise TypeError("conv_gemm_f32_fused: residual must be a channels-last f32 tensor of the output's shape")
+        ldr = n32
+    if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != n32):
+        raise TypeError("conv_gemm_f32_fused: bias must be a contiguous f32 (padded cout,) tensor")
+    check(lib().xm3d_gemm_f32(_ptr(hi), _ptr(lo), B * Ho * Wo, ksize * ksize * cin, 0, _ptr(packs[0]), _ptr(packs[1]), n32, _ptr(bias), 0,
+                              1.0 / (F16T_X_SCALE * sw), _ptr(residual), ldr, _ptr(out), n32, 0, 1, B, H, W, cin, ksize, stride, pt, pl, Ho, Wo, _stream()),
+          "xm3d_gemm_f32")
+    img = out.permute(0, 3, 1, 2)
+    return img if n32 == cout else img[:, :cout].contiguous(memory_format=torch.channels_last)
 
 
 def _f32acc_passes(L_args, terms, packs, out, bias, act, residual, ldr):

@@ -69,9 +69,15 @@ def _packed_cg32(conv):
     """([packed hi, packed lo], column tile, padded cout, padded f32 bias or None) of a frozen f32 Conv2d for ops.conv_gemm_f32"""
     w = conv.weight
     key = (w.data_ptr(), w._version, w.dtype)
+    fused = gemm_f32_fused_on()
+    key = key + (fused,)
     c = conv.__dict__.get("_xm3d_cg32")
     if c is None or c[0] != key:
-        packs, tile, n32 = ops.gemm_pack_weight_f16(w)
+        if fused:
+            packs, _, n32, sw = ops.gemm_pack_weight_f16(w, one_scale=True)
+            tile = ("sw", sw)
+        else:
+            packs, tile, n32 = ops.gemm_pack_weight_f16(w)
         bias = None
         if conv.bias is not None:
             bias = torch.zeros(n32, dtype=torch.float32, device=w.device)
@@ -108,6 +114,9 @@ def own_conv(conv, x, with_bias=True, residual=None, padding=None):
         packs, tile, n32, bias = _packed_cg32(conv)
         if residual is not None and n32 != conv.out_channels:
             return None
+        if isinstance(tile, tuple):
+            return ops.conv_gemm_f32_fused(x, packs, n32, tile[1], conv.out_channels, k[0], conv.stride[0], pad, bias=bias if with_bias else None,
+                                           residual=residual)
         return ops.conv_gemm_f32(x, packs, tile, n32, conv.out_channels, k[0], conv.stride[0], pad, bias=bias if with_bias else None, residual=residual)
     packed, tile, n32, bias = _packed_cg(conv)
     if residual is not None and n32 != conv.out_channels:
@@ -261,6 +270,12 @@ def gemm_f32_on():
     return os.environ.get("XM3D_GEMM_F32", "hip") != "library"
 
 
+def gemm_f32_fused_on():
+    """the one-launch form of the f32-accurate GEMM (both half planes at one scale, three MFMAs per k-step into one accumulator:
+    ops.gemm_f32_fused) unless XM3D_GEMM_F32=passes selects the three accumulating passes (wider activation range: 4e6 instead of 4094)"""
+    return os.environ.get("XM3D_GEMM_F32", "hip") != "passes"
+
+
 def _packed_lin(mods, act=None):
     """(packed weight, column tile, f32 bias or None, rows) of one frozen Linear / 1x1 Conv2d, or of several stacked along the
     output dimension (one GEMM for q, k, v); built once per weight storage and epilogue"""
@@ -284,17 +299,29 @@ def _packed_lin_f32(mods):
     mods = list(mods) if isinstance(mods, (list, tuple)) else [mods]
     key = tuple((m.weight.data_ptr(), m.weight._version, m.weight.dtype) for m in mods)
     cache = mods[0].__dict__.setdefault("_xm3d_gemm", {})
-    c = cache.get((len(mods), "f16split"))
+    fused = gemm_f32_fused_on()
+    c = cache.get((len(mods), "f16split", fused))
     if c is None or c[0] != key:
         w = torch.cat([m.weight.detach().reshape(m.weight.shape[0], -1) for m in mods], 0)
-        packs, tile, n32 = ops.gemm_pack_weight_f16(w)
+        if fused:
+            packs, _, n32, tile = ops.gemm_pack_weight_f16(w, one_scale=True)  # `tile` slot carries the weight scale ("sw", ...) for the fused form
+            tile = ("sw", tile)
+        else:
+            packs, tile, n32 = ops.gemm_pack_weight_f16(w)
         assert n32 == w.shape[0]
         bias = None
         if any(m.bias is not None for m in mods):
             bias = torch.cat([m.bias.detach().float() if m.bias is not None else torch.zeros(m.weight.shape[0], device=w.device)
                               for m in mods]).contiguous()
-        c = cache[(len(mods), "f16split")] = (key, packs, tile, bias, w.shape[0])
+        c = cache[(len(mods), "f16split", fused)] = (key, packs, tile, bias, w.shape[0])
     return c[1:]
+
+
+def _gemm_f32_any(x, packs, n, tile, bias=None, act=None, residual=None):
+    """ops.gemm_f32_fused when `tile` carries a weight scale (("sw", t): the one-launch form), else the three passes of ops.gemm_f32"""
+    if isinstance(tile, tuple):
+        return ops.gemm_f32_fused(x, packs, n, tile[1], bias=bias, act=act, residual=residual)
+    return ops.gemm_f32(x, packs, n, tile, bias=bias, act=act, residual=residual)
 
 
 def lin(mods, x, act=None, residual=None, with_bias=True):
@@ -303,11 +330,11 @@ def lin(mods, x, act=None, residual=None, with_bias=True):
     if x.dtype == torch.float32:
         packs, tile, bias, n = _packed_lin_f32(mods)
         if act == "geglu":
-            return ops.geglu(ops.gemm_f32(x, packs, n, tile, bias=bias if with_bias else None)) if residual is None else \
-                ops.geglu(ops.gemm_f32(x, packs, n, tile, bias=bias if with_bias else None)) + residual
+            return ops.geglu(_gemm_f32_any(x, packs, n, tile, bias=bias if with_bias else None)) if residual is None else \
+                ops.geglu(_gemm_f32_any(x, packs, n, tile, bias=bias if with_bias else None)) + residual
         if residual is not None and not residual.is_contiguous():
             residual = residual.contiguous()
-        return ops.gemm_f32(x, packs, n, tile, bias=bias if with_bias else None, act=act, residual=residual)
+        return _gemm_f32_any(x, packs, n, tile, bias=bias if with_bias else None, act=act, residual=residual)
     packed, tile, bias, n = _packed_lin(mods, act)
     return ops.gemm(x, packed, n, tile, bias=bias if with_bias else None, act=act, residual=residual)
 
@@ -321,12 +348,17 @@ def flinear(x, weight, bias=None, act=None, residual=None):
     (nn.MultiheadAttention's packed in_proj, slices of it); packed images are cached per (storage, shape, version)."""
     n = weight.shape[0]
     if gemm_ok(x, n, act, residual is not None) and weight.dtype == x.dtype and weight.is_contiguous():
-        key = (weight.data_ptr(), tuple(weight.shape), weight._version, weight.dtype, bias.data_ptr() if bias is not None else 0)
+        key = (weight.data_ptr(), tuple(weight.shape), weight._version, weight.dtype, bias.data_ptr() if bias is not None else 0,
+               weight.dtype == torch.float32 and gemm_f32_fused_on())
         c = _FLIN.get(key)
         if c is None:
             b32 = None if bias is None else bias.detach().float().contiguous()
             if weight.dtype == torch.float32:
-                packs, tile, n32 = ops.gemm_pack_weight_f16(weight)
+                if gemm_f32_fused_on():
+                    packs, _, n32, sw = ops.gemm_pack_weight_f16(weight, one_scale=True)
+                    tile = ("sw", sw)
+                else:
+                    packs, tile, n32 = ops.gemm_pack_weight_f16(weight)
                 c = (weight, packs, tile, b32) if n32 == n else None
             else:
                 packed, tile = ops.gemm_pack_weight(weight.detach(), act)
@@ -336,7 +368,7 @@ def flinear(x, weight, bias=None, act=None, residual=None):
             if x.dtype == torch.float32:
                 if residual is not None and not residual.is_contiguous():
                     residual = residual.contiguous()
-                return ops.gemm_f32(x, c[1], n, c[2], bias=c[3], act=act, residual=residual)
+                return _gemm_f32_any(x, c[1], n, c[2], bias=c[3], act=act, residual=residual)
             return ops.gemm(x, c[1], n, c[2], bias=c[3], act=act, residual=residual)
     y = F.linear(x, weight, bias)
     if act == "quick_gelu":
