@@ -515,7 +515,13 @@ def main():
         with torch.no_grad():
             _, cond32, _ = m32.encode_3d(b32["sinput"], b32["inds_reconstruct"], vb32)
             dense32_ms = event_ms(lambda: m32._dense_graphed(b32["img"], cond32), 3) / vb32
+        from xmask3d_amd._lib import lib as _xm3d_lib
+
+        range_flag = int(_xm3d_lib().xm3d_check_flag())  # sticky device flag: an operand left the half's range in a split (must be 0)
+        if range_flag:
+            log(f"fp32 configuration: RANGE FLAG {range_flag} - an activation beyond the split operands' half range; results of this leg are invalid")
         fp32 = {"value": world * args.fp32_steps / dt32, "unit": "scenes/s", "ms_per_step": dt32 / args.fp32_steps * 1e3, "steps": args.fp32_steps,
+                "split_range_flag": range_flag,
                 "scenes_per_forward": G,
                 "dtype": "f32 everywhere, on the 16-bit matrix cores: the sparse 3D convolutions (bf16 x 3 split operands), every dense convolution and "
                          "GEMM of the frozen nets (two-term split in IEEE halves, three accumulating passes, f32 accumulation; <= 1e-6 per layer against f64); "

@@ -239,6 +239,12 @@ def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, lo
         model.train(restore[2])
         if not restore[3]:
             model.enable_dense_graph(False)
+    if dev.type == "cuda":
+        # sticky device flag (coordinates outside the packable range; an activation beyond the half range of a split operand in the fp32
+        # configuration): scores computed past it are not to be trusted - fail loudly instead of reporting them
+        from ._lib import check, lib
+
+        check(lib().xm3d_check_flag(), "inference (device range flag)")
     cs = cfg.category_split
     out = {n: metrics.open_vocab_scores(acc[j, 0], acc[j, 1], cs["base_category"], cs["novel_category"]) for j, n in enumerate(names)}
     if rank == 0:
