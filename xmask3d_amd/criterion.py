@@ -30,10 +30,16 @@ def point_sample(inp, point_coords, **kwargs):
     return out.squeeze(3)
 
 
+def _rand(shape, device):
+    """uniform [0, 1) point coordinates (detectron2's point sampling draws torch.rand on the logits' device); one place, so that a test
+    can make the device run and the CPU oracle draw the SAME points from a host generator"""
+    return torch.rand(*shape, device=device)
+
+
 def get_uncertain_point_coords_with_randomness(logits, uncertainty_func, num_points, oversample_ratio, importance_sample_ratio):
     n = logits.shape[0]
     num_sampled = int(num_points * oversample_ratio)
-    coords = torch.rand(n, num_sampled, 2, device=logits.device)
+    coords = _rand((n, num_sampled, 2), logits.device)
     unc = uncertainty_func(point_sample(logits, coords, align_corners=False))
     num_uncertain = int(importance_sample_ratio * num_points)
     num_random = num_points - num_uncertain
@@ -41,7 +47,7 @@ def get_uncertain_point_coords_with_randomness(logits, uncertainty_func, num_poi
     idx = idx + num_sampled * torch.arange(n, dtype=torch.long, device=logits.device)[:, None]
     coords = coords.view(-1, 2)[idx.view(-1), :].view(n, num_uncertain, 2)
     if num_random > 0:
-        coords = torch.cat([coords, torch.rand(n, num_random, 2, device=logits.device)], dim=1)
+        coords = torch.cat([coords, _rand((n, num_random, 2), logits.device)], dim=1)
     return coords
 
 
@@ -86,7 +92,7 @@ class HungarianMatcher(nn.Module):
             cost_class = -out_prob[:, targets[b]["labels"]]
             out_mask = outputs["pred_masks"][b][:, None].float()
             tgt_mask = targets[b]["masks"].to(out_mask)[:, None]
-            pts = torch.rand(1, self.num_points, 2, device=out_mask.device)  # shared by all masks of the image
+            pts = _rand((1, self.num_points, 2), out_mask.device)  # shared by all masks of the image
             tgt = point_sample(tgt_mask, pts.repeat(tgt_mask.shape[0], 1, 1), align_corners=False).squeeze(1)
             out = point_sample(out_mask, pts.repeat(out_mask.shape[0], 1, 1), align_corners=False).squeeze(1)
             C = self.cost_mask * batch_sigmoid_ce_loss(out, tgt) + self.cost_class * cost_class + self.cost_dice * batch_dice_loss(out, tgt)

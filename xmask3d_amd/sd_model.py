@@ -241,6 +241,7 @@ def plain_conv3x3(conv, x, upsample=False):
 
 # ---- linear layers / 1x1 convolutions on the HIP GEMM (csrc/gemm.hip, xm3d_gemm_bf16)
 _GEMM_LIBRARY = os.environ.get("XM3D_GEMM", "hip") == "library"  # A/B switch: every projection back on torch (hipBLASLt)
+_GEMM_ALL = os.environ.get("XM3D_GEMM", "hip") == "all"          # A/B switch: every eligible bf16 GEMM on k_gemm, also where hipBLASLt is faster
 
 
 def gemm_ok(x, n_rows, act=None, fused_residual=False):
@@ -258,7 +259,9 @@ def gemm_ok(x, n_rows, act=None, fused_residual=False):
         return gemm_f32_on() and x.dim() >= 2 and k % 64 == 0 and n_rows % 32 == 0 and x.numel() > 0
     if x.dtype != torch.bfloat16:
         return False
-    if act == "geglu":
+    if _GEMM_ALL:
+        wins = True
+    elif act == "geglu":
         wins = k <= 320
     else:
         wins = k <= 768 or (fused_residual and k <= 2560 and n_rows <= 640)
@@ -347,6 +350,9 @@ def flinear(x, weight, bias=None, act=None, residual=None):
     where it wins, f32 rows on the f32-accurate GEMM), else torch.  For call sites that hold weight tensors rather than modules
     (nn.MultiheadAttention's packed in_proj, slices of it); packed images are cached per (storage, shape, version)."""
     n = weight.shape[0]
+    if x.dtype == torch.float32 and weight.dtype == torch.bfloat16 and x.is_cuda and not torch.is_grad_enabled() \
+            and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16:
+        x = x.to(torch.bfloat16)  # what autocast does in front of F.linear (bf16 rows out either way); then the own kernel can take it
     if gemm_ok(x, n, act, residual is not None) and weight.dtype == x.dtype and weight.is_contiguous():
         key = (weight.data_ptr(), tuple(weight.shape), weight._version, weight.dtype, bias.data_ptr() if bias is not None else 0,
                weight.dtype == torch.float32 and gemm_f32_fused_on())
