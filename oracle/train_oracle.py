@@ -79,10 +79,13 @@ def cpu_train_ops(model):
 
 def train_step_cpu(model, batch_input):
     """-> (weighted losses dict, outputs) of a CPU-resident fp32 XMASK3d in training mode on a batch whose ``sinput`` is a
-    CpuSparseTensor; gradients are left on the parameters by the caller's ``sum(losses.values()).backward()``."""
+    CpuSparseTensor; the backward of the summed losses runs here too (the deformable-attention backward is an oracle as well), so the
+    parameters' .grad are filled on return."""
     assert model.training
     with cpu_train_ops(model):
-        return model(batch_input)
+        losses, outputs = model(batch_input)
+        sum(losses.values()).backward()
+    return losses, outputs
 
 
 __all__ = ["CpuSparseTensor", "cpu_train_ops", "train_step_cpu"]

@@ -293,8 +293,7 @@ def test_training_iteration_matches_the_cpu_oracle(dev, monkeypatch):
     losses_d, _ = gpu(batch)
     sum(losses_d.values()).backward()
     monkeypatch.setattr(criterion, "_rand", seeded_rand())
-    losses_c, _ = train_oracle.train_step_cpu(cpu, cb)
-    sum(losses_c.values()).backward()
+    losses_c, _ = train_oracle.train_step_cpu(cpu, cb)  # forward + backward
     assert set(losses_d) == set(losses_c) and len(losses_d) >= 37
     worst = 0.0
     for k in sorted(losses_c):

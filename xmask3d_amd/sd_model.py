@@ -241,15 +241,18 @@ def plain_conv3x3(conv, x, upsample=False):
 
 # ---- linear layers / 1x1 convolutions on the HIP GEMM (csrc/gemm.hip, xm3d_gemm_bf16)
 _GEMM_LIBRARY = os.environ.get("XM3D_GEMM", "hip") == "library"  # A/B switch: every projection back on torch (hipBLASLt)
-_GEMM_ALL = os.environ.get("XM3D_GEMM", "hip") == "all"          # A/B switch: every eligible bf16 GEMM on k_gemm, also where hipBLASLt is faster
+# every eligible bf16 GEMM on k_gemm (round 4; end to end 39.49 vs 39.21 scenes/s against the round-3 rule "only where k_gemm wins alone",
+# profiles/r04_bench_gemm_all_ab.log); XM3D_GEMM=wins restores that rule for A/B runs
+_GEMM_ALL = os.environ.get("XM3D_GEMM", "hip") != "wins"
 
 
 def gemm_ok(x, n_rows, act=None, fused_residual=False):
-    """bf16 inference rows on a (K, N) where k_gemm beats the library chain it replaces (tools/gemm_bench.py on MI355X, 20 views,
-    profiles/r03_gemm_bench.log): the HBM-bound projections of the 64^2 / 32^2 UNet levels, the VAE AttnBlock and the cross
-    attention's context projections (K <= 768), plus the feed-forward output projections of the 64^2 / 32^2 levels, where the residual
-    add rides in the epilogue (x1.03 - 1.11).  The MFMA-bound ones (the 16^2 level, the 640 / 1280-wide GEGLU, mask-CLIP) stay on
-    hipBLASLt, which is 1.0 - 1.3 x faster there."""
+    """inference rows that go to the own GEMM kernels: every bf16 (K % 64, N % 32) product on k_gemm, every f32 one on the f32-accurate GEMM.
+    Alone, k_gemm beats the library chain on the HBM-balanced projections (K <= 768, fused residual adds: x1.03 - 1.7) and is
+    0.8 - 0.95 x hipBLASLt on the MFMA-bound ones (the 16^2 level, the wide GEGLUs, mask-CLIP: tools/gemm_bench.py,
+    profiles/r03_gemm_bench.log; 30 % matrix-pipe utilisation on CLIP c_fc, profiles/r04_gemm_pmc.txt: 1.31 tile waves + ~50 % inside a
+    workgroup); in the forward the two balance out (39.49 vs 39.21 scenes/s), so round 4 routes them all here - the library stays
+    behind XM3D_GEMM=wins (the round-3 rule) / =library for A/B runs."""
     if _GEMM_LIBRARY or torch.is_grad_enabled() or not x.is_cuda:
         return False
     k = x.shape[-1]
