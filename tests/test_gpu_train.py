@@ -294,14 +294,14 @@ def test_training_iteration_matches_the_cpu_oracle(dev, monkeypatch):
     sum(losses_d.values()).backward()
     monkeypatch.setattr(criterion, "_rand", seeded_rand())
     losses_c, _ = train_oracle.train_step_cpu(cpu, cb)  # forward + backward
-    assert set(losses_d) == set(losses_c) and len(losses_d) >= 37
+    assert set(losses_d) == set(losses_c) and len(losses_d) >= 36  # 36 + loss_3d_contra from cfg.start_contra on
     worst = 0.0
     for k in sorted(losses_c):
         a, b = float(losses_d[k]), float(losses_c[k])
         rel = abs(a - b) / max(abs(b), 1e-6)
         worst = max(worst, rel)
         print(f"[train parity] {k:32s} device {a:.6f} oracle {b:.6f} rel {rel:.2e}")
-        assert rel < 2e-3, (k, a, b)  # measured: see the printed table (f32 nets 870 layers deep on two back ends; discrete top-k of the point sampling)
+        assert rel < 1e-4, (k, a, b)  # measured <= 8.5e-6 (most <= 2e-7): profiles/r04_train_parity.log
     names = ["criterion.fuser.linear.weight", "pc_decoder.decoder.weight", "pc_decoder.encoder.conv0p1s1.kernel",
              "sem_seg_head.pixel_decoder.input_proj.0.0.weight", "sem_seg_head.predictor.decoder_norm.weight",
              "backbone.feature_projections.0.0.conv3.weight"]
@@ -311,4 +311,5 @@ def test_training_iteration_matches_the_cpu_oracle(dev, monkeypatch):
         assert gd is not None and gc is not None, n
         rel = float((gd.cpu() - gc).abs().max() / gc.abs().max().clamp_min(1e-20))
         print(f"[train parity] grad {n:55s} rel {rel:.2e}")
-        assert rel < 5e-2, (n, rel)
+        # measured 4e-6 .. 2.5e-4 for the heads, 2.3e-2 for the sparse stem's kernel (the gradient after ~55 sparse layers, f32 atomics in wgrad)
+        assert rel < (5e-2 if "conv0p1s1" in n else 2e-3), (n, rel)
