@@ -110,52 +110,77 @@ def conv_roofline(dev):
             "library_conv_alone_us": ms_lib * 1e3, "library_conv_alone_frac": flop / (ms_lib * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF}
 
 
+def _spconv_forms(dev, cm, ts, cin, cout, seed, reps=20):
+    """One sparse-conv layer (k = 3 at tensor stride `ts`) in both forms the forward uses, measured live with HIP events:
+    the plain-bf16 form (bf16 configuration: one bf16 plane in / out, one MFMA per product) and the f32-accurate split form (fp32
+    configuration and training: f32 rows + pre-split bf16 hi / lo copies in and out, three MFMAs per product).  SURVEY 8d prices the
+    sparse convolution against HBM on the gather + scatter model: bytes = pairs * (cin + cout) * e + 8 * pairs + K * cin * cout * e;
+    the matrix rate executed is listed against the bf16 MFMA peak the instructions actually run on."""
+    from xmask3d_amd import ops
+
+    nbr, tiles, order = cm.kernel_map(ts, ts, 3), cm.tiles(ts, ts, 3), cm.order(ts)
+    n = cm.num(ts)
+    pairs = int((nbr >= 0).sum().item())
+    g = torch.Generator(device="cpu").manual_seed(seed)
+    feats = torch.randn(n, cin, generator=g).to(dev)
+    W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev)
+    p4 = ops.pack_weight_split(W)
+    fb = feats.bfloat16().contiguous()
+    fs = torch.stack([feats.bfloat16(), (feats - feats.bfloat16().float()).bfloat16()]).contiguous()
+    ms_bf = event_ms(lambda: ops.spconv_fwd_bf16(fb, tuple(W.shape), p4, tiles, n, order=order, relu=True), reps)
+    ms_sp = event_ms(lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=p4, tiles=tiles, relu=True, algo=ops.ALGO_SPLIT, feats_split=fs,
+                                            want_split=True), reps)
+    flop = 2.0 * pairs * cin * cout
+
+    def model_bytes(e):
+        return pairs * (cin + cout) * e + pairs * 8 + 27 * cin * cout * e
+
+    def form(ms, e, mfmas, compulsory):
+        gs = model_bytes(e)
+        tf = flop / (ms * 1e-3) / 1e12
+        return {"avg_launch_us": ms * 1e3, "algorithmic_bytes_gather_scatter": gs, "gather_scatter_GBps": gs / (ms * 1e-3) / 1e9,
+                "frac_of_hbm_peak": gs / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "algorithmic_bytes_compulsory": compulsory,
+                "algorithmic_TFLOPs": tf, "executed_bf16_TFLOPs": mfmas * tf, "executed_frac_of_bf16_mfma_peak": mfmas * tf / BF16_MFMA_PEAK_TF}
+
+    bf = form(ms_bf, 2, 1, 2 * n * cin * 2 + 27 * cin * cout * 2 + 8 * pairs)
+    sp = form(ms_sp, 4, 3, (2 * n * cin + 27 * cin * cout) * 4 + 2 * n * cout * 2 + 8 * pairs)
+    sp["algorithmic_frac_of_f32_matrix_peak"] = sp["algorithmic_TFLOPs"] / FP32_MFMA_PEAK_TF
+    return {"pairs": pairs, "voxels": n, "cin": cin, "cout": cout}, bf, sp, (feats, W, nbr, n, order, tiles)
+
+
+def _spconv_object(kernel_bf, kernel_sp, meta, bf, sp):
+    out = {"kernel": kernel_bf, "bound": "hbm", "achieved": bf["gather_scatter_GBps"], "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": bf["frac_of_hbm_peak"], "traffic": pmc_traffic(kernel_bf)}
+    out.update(meta)
+    out.update({k: v for k, v in bf.items() if k not in ("gather_scatter_GBps", "frac_of_hbm_peak")})
+    sp = dict(sp, kernel=kernel_sp, traffic=pmc_traffic(kernel_sp))
+    out["f32_accurate_form"] = sp
+    return out
+
+
 def spconv_roofline(dev):
-    """Roofline of the dominant hand-written kernel, k_spconv_split (algo 4), on the S1-full 96->96 k=3 layer at tensor
-    stride 1 (MinkUNet34C block8): algorithmic FLOP = 2*P*Cin*Cout, bytes = gather+scatter model.  The
-    kernel computes every f32 product as three bf16 MFMAs, so `achieved` (algorithmic TFLOP/s) is priced against the F32
-    matrix peak (157.3 TF = what an exact-f32 kernel could reach at best); the executed bf16 rate is listed beside it."""
+    """`roofline_spconv`: the dominant kernel of the sparse 3D branch on the S1-full 96 -> 96 k = 3 layer at tensor stride 1 (MinkUNet34C
+    block8, 107 k voxels, 418 k pairs): the plain-bf16 form the bf16 configuration runs (headline object, HBM roofline on the gather +
+    scatter model as SURVEY 8d prices it) and, under `f32_accurate_form`, the split-operand form of the fp32 configuration."""
     from xmask3d_amd import ops, synthetic
 
     sc = synthetic.scene_s1()
-    T = np.diag([50.0, 50.0, 50.0, 1.0])
-    grid, inds, inv = ops.voxelize(torch.from_numpy(sc.points).to(dev), T)
+    grid, inds, inv = ops.voxelize(torch.from_numpy(sc.points).to(dev), np.diag([50.0, 50.0, 50.0, 1.0]))
     coords = torch.cat([torch.zeros(grid.shape[0], 1, dtype=torch.int32, device=dev), grid], 1).contiguous()
     cm = ops.CoordinateManager(coords)
-    n = coords.shape[0]
-    nbr, tiles, order = cm.kernel_map(1, 1, 3), cm.tiles(1, 1, 3), cm.order(1)
-    pairs = int((nbr >= 0).sum().item())
-    cin = cout = 96
-    g = torch.Generator(device="cpu").manual_seed(1)
-    feats = torch.randn(n, cin, generator=g).to(dev)
-    W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev)
-    p4, p3 = ops.pack_weight_split(W), ops.pack_weight(W)
-    # as the layer runs inside MinkUNet34C block8: the input arrives with its pre-split bf16 hi/lo copy (written by the previous
-    # conv's epilogue) and the epilogue writes the copy for the next conv
-    fs = torch.stack([feats.bfloat16(), (feats - feats.bfloat16().float()).bfloat16()]).contiguous()
-    ms = event_ms(lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=p4, tiles=tiles, relu=True, algo=ops.ALGO_SPLIT,
-                                         feats_split=fs, want_split=True), 20)
-    ms_f32in = event_ms(lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=p4, tiles=tiles, relu=True, algo=ops.ALGO_SPLIT), 10)
+    meta, bf, sp, (feats, W, nbr, n, order, tiles) = _spconv_forms(dev, cm, 1, 96, 96, 1)
+    out = _spconv_object("k_spconv_split<6,1,96,4,3,2,true,true,1>", "k_spconv_split<6,1,96,4,3,2,true,false,1>", meta, bf, sp)
+    p3 = ops.pack_weight(W)
     ms3 = event_ms(lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=p3, tiles=tiles, relu=True, algo=ops.ALGO_TILES), 10)
-    flop = 2.0 * pairs * cin * cout
-    gs_bytes = pairs * (cin + cout) * 4 + pairs * 8 + 27 * cin * cout * 4
-    tf = flop / (ms * 1e-3) / 1e12
-    return {"kernel": "xm3d::k_spconv_split<6,1,96,4,3,2,true>", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF,
-            "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF,
-            # HBM-side bytes per launch from rocprofv3 PMC passes on `bench.py --roofline-only` (profiles/r02_roofline_spconv_pmc.txt)
-            "traffic": pmc_traffic("k_spconv_split<6,1,96,4,3,2,true>"), "algorithmic_bytes_gather_scatter": gs_bytes,
-            "algorithmic_bytes_compulsory": (2 * n * cin + 27 * cin * cout) * 4 + 8 * pairs,
-            "avg_launch_us": ms * 1e3, "pairs": pairs, "voxels": n, "cin": cin, "cout": cout,
-            "gather_scatter_GBps": gs_bytes / (ms * 1e-3) / 1e9,
-            "executed_bf16_TFLOPs": 3 * tf, "executed_frac_of_bf16_peak": 3 * tf / BF16_MFMA_PEAK_TF,
-            "f32_input_split_on_the_fly_us": ms_f32in * 1e3, "exact_f32_kernel_us": ms3 * 1e3, "exact_f32_kernel_frac": flop / (ms3 * 1e-3) / 1e12 / FP32_MFMA_PEAK_TF}
+    out["exact_f32_kernel_us"] = ms3 * 1e3
+    return out
 
 
 def sparse_network_roofline(dev, model):
     """`roofline_sparse_network`: both sparse U-Nets (MinkUNet34C + MinkUNet18A, heads included) on the FULL S1 cloud (S1-full, SURVEY
-    8d: 106 950 voxels): algorithmic 379.3 GFLOP (convolutions, measured pair counts) + 42.6 GFLOP (heads) per forward / measured
-    time, against the f32 matrix peak the split-operand kernels are priced on.  HIP events around whole forwards (rulebooks included:
-    they are rebuilt every forward, as in training)."""
+    8d: 106 950 voxels) in the form the benched model runs them (bf16 configuration: plain-bf16 convolutions): algorithmic 379.3 GFLOP
+    (convolutions, measured pair counts) + 42.6 GFLOP (heads) per forward / measured time, against the bf16 matrix peak the kernels
+    execute on.  HIP events around whole forwards (rulebooks included: they are rebuilt every forward, as in training)."""
     from xmask3d_amd import me_compat as ME, ops, synthetic
 
     sc = synthetic.scene_s1()
@@ -172,38 +197,28 @@ def sparse_network_roofline(dev, model):
     ms = event_ms(once, 5)
     gflop = 379.3 + 42.6
     tf = gflop / ms  # GFLOP / ms = TFLOP/s
-    return {"kernel": "MinkUNet34C + MinkUNet18A on S1-full (k_spconv_split / k_spconv_tiles + rulebook kernels)", "bound": "mfma", "achieved": tf,
-            "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": tf / FP32_MFMA_PEAK_TF, "ms_per_forward": ms, "voxels": int(coords.shape[0]),
-            "algorithmic_gflop": gflop, "note": "network level: coordinate / rulebook kernels, BatchNorm folding and the two Linear heads inside the time"}
+    form = "plain-bf16" if getattr(model, "sparse_dtype", None) == torch.bfloat16 else "f32-accurate split (3 MFMAs per product)"
+    mf = 1 if form == "plain-bf16" else 3
+    return {"kernel": "MinkUNet34C + MinkUNet18A on S1-full (k_spconv_split + rulebook kernels), " + form + " form", "bound": "mfma",
+            "achieved": mf * tf, "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s (executed)", "frac": mf * tf / BF16_MFMA_PEAK_TF, "algorithmic_TFLOPs": tf,
+            "ms_per_forward": ms, "voxels": int(coords.shape[0]), "algorithmic_gflop": gflop,
+            "note": "network level: coordinate / rulebook kernels, BatchNorm folding and the two Linear heads inside the time; the sparse branch is "
+                    "latency / gather bound, nowhere near the matrix roof: per-layer HBM rooflines are `roofline_spconv` / `roofline_spconv_window`"}
 
 
 def spconv_window_roofline(dev, sd, voxelizer, n_views):
-    """`roofline_spconv_window`: the sparse-conv instantiation with the largest share of the timed window, k_spconv_split<4,1,64,8,3,2,true>
-    = the 64 -> 64 channel k = 3 layers at tensor stride 2 (MinkUNet block 2), on the coordinates of the bench forward itself (`n_views`
-    views in one batch), pre-split input and split output as inside the network; pair count read live from the kernel map."""
+    """`roofline_spconv_window`: the sparse-conv instantiation with the largest share of the timed window - the 64 -> 64 channel k = 3 layers at
+    tensor stride 2 (MinkUNet block 2) - on the coordinates of the bench forward itself (`n_views` views in one batch), pair count read
+    live from the kernel map; both forms as in `roofline_spconv`."""
     from xmask3d_amd import ops, pipeline
 
     mats = [np.diag([50.0, 50.0, 50.0, 1.0])] * n_views
     batch = pipeline.build_scene_batch(sd, [i % len(sd.views) for i in range(n_views)], voxelizer, mats)
-    cm = ops.CoordinateManager(batch["coords"] if "coords" in batch else batch["sinput"].C)
-    nbr, tiles, order = cm.kernel_map(2, 2, 3), cm.tiles(2, 2, 3), cm.order(2)
-    n = cm.num(2)
-    pairs = int((nbr >= 0).sum().item())
-    cin = cout = 64
-    g = torch.Generator(device="cpu").manual_seed(2)
-    feats = torch.randn(n, cin, generator=g).to(dev)
-    W = (torch.randn(27, cin, cout, generator=g) * 0.05).to(dev)
-    p4 = ops.pack_weight_split(W)
-    fs = torch.stack([feats.bfloat16(), (feats - feats.bfloat16().float()).bfloat16()]).contiguous()
-    ms = event_ms(lambda: ops.spconv_fwd(feats, W, nbr, n, order=order, packed=p4, tiles=tiles, relu=True, algo=ops.ALGO_SPLIT, feats_split=fs,
-                                         want_split=True), 20)
-    flop = 2.0 * pairs * cin * cout
-    tf = flop / (ms * 1e-3) / 1e12
-    return {"kernel": "xm3d::k_spconv_split<4,1,64,8,3,2,true>", "bound": "mfma", "achieved": tf, "peak": FP32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-            "frac": tf / FP32_MFMA_PEAK_TF, "traffic": pmc_traffic("k_spconv_split<4,1,64,8,3,2,true>"), "avg_launch_us": ms * 1e3, "pairs": pairs,
-            "voxels": n, "cin": cin, "cout": cout, "views": n_views,
-            "algorithmic_bytes_gather_scatter": pairs * (cin + cout) * 4 + pairs * 8 + 27 * cin * cout * 4,
-            "algorithmic_bytes_compulsory": (2 * n * cin + 27 * cin * cout) * 4 + 8 * pairs}
+    cm = ops.CoordinateManager(batch["sinput"].C)
+    meta, bf, sp, _ = _spconv_forms(dev, cm, 2, 64, 64, 2)
+    out = _spconv_object("k_spconv_split<4,1,64,8,3,2,true,true,1>", "k_spconv_split<4,1,64,8,3,2,true,false,1>", meta, bf, sp)
+    out["views"] = n_views
+    return out
 
 
 def kernel_rooflines(dev):
@@ -236,6 +251,21 @@ def kernel_rooflines(dev):
     out.append({"kernel": "xm3d::k_gn_stats_nhwc + k_gn_apply_nhwc <bf16>", "bound": "hbm", "achieved": nbytes / (ms * 1e-3) / 1e9,
                 "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, "avg_launch_us": ms * 1e3,
                 "algorithmic_bytes": nbytes, "note": "two reads + one write of a (5,256,256,256) bf16 map, both launches"})
+    # implicit-GEMM convolution (k_gemm, rows gathered from the NHWC image while staging): the two instantiations with the largest share
+    for name, cin, cout, h, k, stride, pad in (("SD VAE downsample 512 -> 512, 3x3 stride 2, 128^2 -> 64^2", 512, 512, 128, 3, 2, (0, 0, 1, 1)),
+                                                ("SD UNet ResnetBlock 2560 -> 1280, 3x3, 16^2 (split-K 2, f32 slabs + fixed-order finish)", 2560, 1280, 16, 3, 1,
+                                                 (1, 1, 1, 1))):
+        xc = torch.randn(20, cin, h, h, generator=g).to(dev, torch.bfloat16).contiguous(memory_format=torch.channels_last)
+        wc = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev, torch.bfloat16)
+        packed, tile, n32 = ops.conv_gemm_pack_weight(wc)
+        bpad = torch.zeros(n32, device=dev)
+        ms = event_ms(lambda: ops.conv_gemm(xc, packed, tile, n32, cout, k, stride, pad, bias=bpad), 10)
+        ho = (h + pad[0] + pad[2] - k) // stride + 1
+        fl = 2.0 * 20 * ho * ho * cin * k * k * cout
+        nb = (xc.numel() + wc.numel() + 20 * ho * ho * cout) * 2
+        out.append({"kernel": "xm3d::k_gemm<..., GF_CONV> (implicit GEMM convolution)", "bound": "mfma", "achieved": fl / (ms * 1e-3) / 1e12,
+                    "peak": BF16_MFMA_PEAK_TF, "unit": "TFLOP/s", "frac": fl / (ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TF, "avg_launch_us": ms * 1e3,
+                    "algorithmic_bytes": nb, "note": name + ", 20 views, bf16 NHWC in / out, f32 accumulation, bias in the epilogue"})
     # exact nearest neighbour fill: 120 k queries x 40 k references, VALU bound: 8 flop per (query, reference)
     q = torch.rand(120000, 3, generator=g).to(dev)
     r = torch.rand(40000, 3, generator=g).to(dev)
@@ -603,12 +633,14 @@ def main():
     roofline["scope"] = ("time-dominant hand-written HIP kernel (fused GroupNorm-SiLU-conv3x3 of the SD VAE / UNet ResnetBlocks); algorithmic "
                          "FLOP = 2*B*H*W*9*Cin*Cout per launch, one launch = one ResnetBlock convolution of the VAE at 128x128 on 20 views")
     roofline_spconv = spconv_roofline(dev)
-    roofline_spconv["scope"] = ("dominant kernel of the sparse 3D branch; algorithmic FLOP = 2*pairs*cin*cout per launch (SURVEY 8d), one launch = "
-                                "one sparse-conv layer of MinkUNet34C block8 on the full S1 cloud")
+    roofline_spconv["scope"] = ("dominant kernel of the sparse 3D branch, HBM roofline on the gather + scatter byte model of SURVEY 8d (pairs*(cin+cout)*e "
+                                "+ 8*pairs + K*cin*cout*e per launch), one launch = one sparse-conv layer of MinkUNet34C block8 on the full S1 cloud; "
+                                "headline object = the plain-bf16 form the bf16 configuration runs, `f32_accurate_form` = the split-operand form of the "
+                                "fp32 configuration and of training; matrix rates are listed against the bf16 MFMA peak the instructions execute on")
     roofline_stage = {"bound": "mfma", "achieved": dense_tflop / (dense_ms * 1e-3), "peak": peak, "unit": "TFLOP/s",
                       "frac": dense_tflop / (dense_ms * 1e-3) / peak, "traffic": None, "views_per_forward": vb,
                       "scope": "dense 2D branch per view (SD VAE+UNet, projections, pixel+transformer decoder, mask-CLIP): HIP fused GroupNorm-SiLU-conv3x3 "
-                               "for the ResnetBlocks, MIOpen / hipBLASLt for the other convolutions / GEMMs, HIP flash attention (VAE d=512 head: GEMM + HIP row softmax + GEMM) + HIP GroupNorm / LayerNorm / pointwise kernels, " + ("HIP graph replay" if not args.no_graph else "eager launches"),
+                               "for the ResnetBlocks, HIP implicit-GEMM k_gemm for the other convolutions and the linear layers (MIOpen only for the cin < 64 stems), HIP flash attention (VAE d=512 head: GEMM + HIP row softmax + GEMM) + HIP GroupNorm / LayerNorm / pointwise kernels, " + ("HIP graph replay" if not args.no_graph else "eager launches"),
                       "ms_per_view": dense_ms, "algorithmic_tflop_per_view": dense_tflop, "sparse3d_ms_per_view": sparse_ms}
 
     cpu_baseline = None
@@ -628,8 +660,8 @@ def main():
     out = {
         "metric": "ScanNet scenes/sec (infer)", "value": value, "unit": "scenes/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype + " (frozen SD/CLIP nets, decoder GEMMs) + f32 (deformable attention, statistics, logits; sparse 3D: f32 in/out, "
-                 "products as bf16x3 split operands with f32 accumulation)", "data": "synthetic",
+        "dtype": args.dtype + " (frozen SD/CLIP nets, decoder GEMMs) + f32 (deformable attention, statistics, logits); sparse 3D: " + ("bf16 rows, bf16 products, f32 accumulation"
+                 if getattr(model, "sparse_dtype", None) == torch.bfloat16 else "f32 rows, products as bf16x3 split operands with f32 accumulation"), "data": "synthetic",
         "config": {"workload": f"ScanNet B15N4 inference, synthetic scenes S1 ({len(scenes)} distinct seeds, ~120k pts, 5 views 240x320->512x512), "
                                f"{vb} views ({G} scene{'s' if G > 1 else ''}) per forward, seeded random weights", "views_per_scene": n_views, "parallelism": f"dp{world} (scene level, no collective)",
                    "dead_compute": "as reference" if args.faithful_dead_compute else "pruned (SURVEY F7)",

@@ -11,7 +11,7 @@ def collect(d, sub):
     for f in sorted(glob.glob(d + "/**/*counter_collection.csv", recursive=True)):
         agg = collections.defaultdict(list)
         for r in csv.DictReader(open(f)):
-            if sub in r["Kernel_Name"]:
+            if any(a in r["Kernel_Name"] for a in sub.split("|")):     # `a|b`: either spelling (mangled / demangled)
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, v in agg.items():
             out[k] = (f, v)
