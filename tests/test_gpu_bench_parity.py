@@ -216,3 +216,17 @@ def test_other_benchmark_configs_match_oracle_per_stage(dev, name):
         for k, bound in FP32.items():
             assert rep[k] <= bound, f"{name}: {k} = {rep[k]:.3e} > {bound:.1e}"
         assert rep["binary_agree"] > 0.999 and rep["ownership_agree"] > 0.995 and rep["point_label_agree"] > 0.9995
+    if name.endswith("B170N30"):
+        # the bench (bf16) configuration on the 200-class head, against the SAME oracle view: the measured bf16 budgets of B15N4 hold
+        # (the class count only widens the text matrix of the last product)
+        del model
+        fast = pipeline.make_inference_model(cpu, dev, torch.bfloat16, channels_last=True, graphs=True)
+        batch, out = _forward_group(fast, [pipeline.SceneOnDevice(scene, dev)], vox)
+        off = batch["point_offsets"]
+        rep = stage_report(out, 4, slice(off[4], off[5]), oracle_view(cpu, scene, 4, (name, 4)))
+        print(f"[parity {name} bf16 view 4] " + " ".join(f"{k}={x:.3e}" for k, x in rep.items()))
+        assert rep["clip_queries_flipped"] <= 2
+        for k, bound in BF16.items():
+            assert rep[k] <= bound, f"{name} bf16: {k} = {rep[k]:.3e} > {bound:.1e}"
+        # 200 classes with random text rows: neighbouring classes sit closer than with 19, so more labels flip inside the same budget
+        assert rep["binary_agree"] > 0.999 and rep["ownership_agree"] > 0.92 and rep["point_label_agree"] > 0.90

@@ -1,5 +1,5 @@
 """Device time of the elementwise / copy aten ops of the dense branch (eager, bench configuration) attributed to the
-xmask3d_amd source line that issued them.  python tools/prof_lines.py [B]"""
+xmask3d_amd source line that issued them.  python tools/prof_lines.py [B] [fp32|bf16] [lib] [all]"""
 import sys, os, collections
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch
@@ -37,6 +37,8 @@ with torch.no_grad():
         model.dense_forward(batch["img"], cond)
     torch.cuda.synchronize()
     with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True, record_shapes=True) as prof:
+        if "all" in sys.argv[2:]:  # python tools/prof_lines.py 20 bf16 all: the sparse 3D branch inside the profile too
+            model.encode_3d(batch["sinput"], batch["inds_reconstruct"], B)
         model.dense_forward(batch["img"], cond)
         torch.cuda.synchronize()
 skip = ("convolution", "mm", "bmm", "linear", "layer_norm", "group_norm", "attention", "softmax", "MSDeform", "conv2d", "matmul")
