@@ -305,7 +305,7 @@ def train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log, train_dt
     tdt = torch.bfloat16 if train_dtype == "bf16" else torch.float32
     torch.manual_seed(cfg.manual_seed)
     model = XMASK3d(cfg).to(dev).set_dense_dtype(tdt).train()
-    model.backbone.feature_extractor.ldm_extractor.enable_train_graph()
+    model.enable_train_graphs()
     if world > 1:
         ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)  # per-GPU batch < 4 (run/train.py:185-187)
         torch.nn.SyncBatchNorm.convert_sync_batchnorm(model)

@@ -313,3 +313,25 @@ def test_training_iteration_matches_the_cpu_oracle(dev, monkeypatch):
         print(f"[train parity] grad {n:55s} rel {rel:.2e}")
         # measured 4e-6 .. 2.5e-4 for the heads, 2.3e-2 for the sparse stem's kernel (the gradient after ~55 sparse layers, f32 atomics in wgrad)
         assert rel < (5e-2 if "conv0p1s1" in n else 2e-3), (n, rel)
+
+    # the same iteration with the static stages replayed as HIP graphs (XMASK3d.enable_train_graphs: frozen UNet forward + backward,
+    # frozen VAE stages on the inference kernels, the trainable dense heads forward + backward) against the eager device iteration
+    graphed = copy.deepcopy(cpu).to(dev).train()
+    for p in graphed.parameters():
+        p.grad = None
+    graphed.enable_train_graphs()
+    for rep in range(2):  # the second pass replays what the first captured
+        for p in graphed.parameters():
+            p.grad = None
+        monkeypatch.setattr(criterion, "_rand", seeded_rand())
+        losses_g, _ = graphed(batch)
+        sum(losses_g.values()).backward()
+        for k in sorted(losses_d):
+            a, b = float(losses_g[k]), float(losses_d[k])
+            assert abs(a - b) / max(abs(b), 1e-6) < 1e-4, (rep, k, a, b)
+        pg = dict(graphed.named_parameters())
+        for n in names:
+            rel = float((pg[n].grad - pd[n].grad).abs().max() / pd[n].grad.abs().max().clamp_min(1e-20))
+            print(f"[train graphs pass {rep}] grad {n:55s} rel to eager {rel:.2e}")
+            assert rel < (5e-2 if "conv0p1s1" in n else 2e-3), (rep, n, rel)
+    assert graphed._head_graphs and graphed.backbone.feature_extractor.ldm_extractor._vae_graphs

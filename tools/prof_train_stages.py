@@ -15,7 +15,7 @@ model = XMASK3d(cfg).to(dev).set_dense_dtype(dtype).train()
 if "cl" in sys.argv[2:]:
     model.set_channels_last(True)
 if "graph" in sys.argv[2:]:
-    model.backbone.feature_extractor.ldm_extractor.enable_train_graph()
+    model.enable_train_graphs()
 opt = torch.optim.AdamW([p for p in model.parameters() if p.requires_grad], lr=1e-4, fused=True)
 sd = pipeline.SceneOnDevice(synthetic.scene_s1(), dev)
 vox = pipeline.default_voxelizer(device=dev)

@@ -23,7 +23,7 @@ model = XMASK3d(cfg).to(dev).set_dense_dtype(dtype).train()
 if "cl" in sys.argv[3:]:
     model.set_channels_last(True)
 if "graph" in sys.argv[3:]:
-    model.backbone.feature_extractor.ldm_extractor.enable_train_graph()
+    model.enable_train_graphs()
 if world > 1:
     ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)      # per-GPU batch < 4 (run/train.py:185-187)
     model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local], find_unused_parameters=False)

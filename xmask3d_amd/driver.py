@@ -91,8 +91,9 @@ def train(cfg, epochs=1, iters_per_epoch=4, views_per_gpu=2, save_path=None, res
     model = XMASK3d(cfg).to(dev)
     _log_pretrained(model, log)
     if dev.type == "cuda" and bool(getattr(cfg, "train_unet_graph", True)):
-        # the frozen UNet's forward + backward replay as HIP graphs (it has no trainable parameter: DDP never sees it)
-        model.backbone.feature_extractor.ldm_extractor.enable_train_graph()
+        # static-shape stages replay as HIP graphs: frozen UNet forward + backward, frozen VAE stages, the trainable dense heads
+        # (XMASK3d.enable_train_graphs; parameter gradients still arrive through AccumulateGrad, so DDP is unchanged)
+        model.enable_train_graphs()
     if world > 1:
         if views_per_gpu < 4:
             ME.MinkowskiSyncBatchNorm.convert_sync_batchnorm(model)

@@ -171,16 +171,58 @@ class LdmExtractor(nn.Module):
     def encode(self, img):
         """VAE encoder stage: img (B,3,H,W) in [0,1] -> (latent (B,4,H/8,W/8), tapped encoder features).  Independent of the
         3D conditioning, so it can run concurrently with the sparse 3D branch."""
+        if self._vae_graph_ok(img):
+            return self._vae_graphed("enc", self._encode, img)
+        return self._encode(img)
+
+    def _encode(self, img):
         ldm = self.ldm
         x = (img - ldm.pixel_mean.to(img.dtype)) / ldm.pixel_std.to(img.dtype)
+        if self._vae_train_nhwc:
+            x = x.contiguous(memory_format=torch.channels_last)
         moments, enc_feats = ldm.encoder(x, taps=self.encoder_block_indices)
         moments = ldm.first_stage_model.quant_conv(moments)
+        if self._vae_train_nhwc:  # the UNet and the trainable projections (library kernels under autograd) keep NCHW
+            moments, enc_feats = moments.contiguous(), [f.contiguous() for f in enc_feats]
         return SCALE_FACTOR * moments[:, :4], enc_feats  # posterior mean
 
     @torch.no_grad()  # depends on the image only (through the latent): no gradient path to any trainable parameter
     def decode_taps(self, latent):
-        z = self.ldm.first_stage_model.post_quant_conv(latent / SCALE_FACTOR)
-        return self.ldm.decoder(z, taps=self.decoder_block_indices, stop_after_taps=self.prune_dead_compute)[1]
+        if self._vae_graph_ok(latent):
+            return self._vae_graphed("dec", self._decode_taps, latent)
+        return self._decode_taps(latent)
+
+    def _decode_taps(self, latent):
+        z = latent / SCALE_FACTOR
+        if self._vae_train_nhwc:
+            z = z.contiguous(memory_format=torch.channels_last)
+        z = self.ldm.first_stage_model.post_quant_conv(z)
+        taps = self.ldm.decoder(z, taps=self.decoder_block_indices, stop_after_taps=self.prune_dead_compute)[1]
+        return [f.contiguous() for f in taps] if self._vae_train_nhwc else taps
+
+    _vae_train_nhwc = False
+    _vae_graphs = None
+
+    def enable_vae_train_path(self, on=True):
+        """Training: the frozen, gradient-free VAE stages (encoder, decoder taps) take the inference kernels - channels-last weights, the
+        f32-accurate split-operand convolutions / GEMMs on the matrix cores instead of the library's f32 Winograd kernels - and replay
+        as one HIP graph each (train_graph.GraphedNoGrad).  Their taps go back to NCHW for the UNet and the trainable projections."""
+        self._vae_train_nhwc = on
+        self._vae_graphs = {} if on else None
+        self.ldm.first_stage_model.to(memory_format=torch.channels_last if on else torch.contiguous_format)
+        return self
+
+    def _vae_graph_ok(self, x):
+        return self._vae_graphs is not None and x.is_cuda and not torch.cuda.is_current_stream_capturing()
+
+    def _vae_graphed(self, which, fn, x):
+        from .train_graph import GraphedNoGrad
+
+        key = (which, tuple(x.shape), x.dtype)
+        g = self._vae_graphs.get(key)
+        if g is None:
+            g = self._vae_graphs[key] = GraphedNoGrad(fn, [x])
+        return g(x)
 
     def unet_taps(self, latent, cond_inputs, cond_emb):
         noise = self.shared_noise.to(latent.dtype)
@@ -397,21 +439,28 @@ class FeatureExtractorBackbone(nn.Module):
             img = F.interpolate(img, size=self.backbone_in_size, mode="bicubic", align_corners=False)
         return img
 
+    def extract(self, img, imp_condition, encoded=None, fork_stream=None):
+        """the frozen extractor's 8 feature maps (no trainable parameter below this point except the conditioning projections)"""
+        img = self.prepare(img)
+        # the frozen extractor runs natively in img.dtype (bf16 weights: no autocast casts, GroupNorm stays bf16 I/O)
+        inputs = dict(img=img)
+        if encoded is not None:
+            inputs.update(latent=encoded[0], enc_feats=encoded[1], fork_stream=fork_stream)
+        return self.feature_extractor(inputs, imp_condition)
+
+    def project(self, feats, size, low):
+        """the trainable fp32 projections; under autocast when the features are bf16"""
+        dev = feats[0].device.type
+        with torch.autocast(device_type=dev, dtype=feats[0].dtype if low else torch.bfloat16, enabled=low):
+            if self.use_checkpoint and torch.is_grad_enabled() and not torch.cuda.is_current_stream_capturing():
+                from torch.utils.checkpoint import checkpoint
+
+                return checkpoint(self.forward_features, feats, size, use_reentrant=False)
+            return self.forward_features(feats, size)
+
     def forward(self, img, imp_condition, encoded=None, fork_stream=None):
         """img (B,3,H,W) in [0,1] (H=W=512 in every XMask3D config -> one 1x1 sliding window, feature_extractor.py:169-226).
         encoded = (latent, enc_feats) from ``feature_extractor.ldm_extractor.encode(prepare(img))`` skips the VAE encoder."""
         h, w = img.shape[-2:]
-        img = self.prepare(img)
-        # the frozen extractor runs natively in img.dtype (bf16 weights: no autocast casts, GroupNorm stays bf16 I/O);
-        # the trainable fp32 projections run under autocast when the features are bf16
-        inputs = dict(img=img)
-        if encoded is not None:
-            inputs.update(latent=encoded[0], enc_feats=encoded[1], fork_stream=fork_stream)
-        feats = self.feature_extractor(inputs, imp_condition)
-        low = img.dtype != torch.float32
-        with torch.autocast(device_type=img.device.type, dtype=img.dtype if low else torch.bfloat16, enabled=low):
-            if self.use_checkpoint and torch.is_grad_enabled():
-                from torch.utils.checkpoint import checkpoint
-
-                return checkpoint(self.forward_features, feats, (h, w), use_reentrant=False)
-            return self.forward_features(feats, (h, w))
+        feats = self.extract(img, imp_condition, encoded, fork_stream)
+        return self.project(feats, (h, w), img.dtype != torch.float32)

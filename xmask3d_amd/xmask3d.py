@@ -235,7 +235,44 @@ class XMASK3d(nn.Module):
     def encode_2d(self, img, imp_condition_input, encoded=None, fork_stream=None):
         """img (B,3,H,W) 0..255 -> decoder outputs (the training forward adds category head and losses itself)."""
         img = img.to(imp_condition_input.device)
+        if self._head_graphs is not None and torch.is_grad_enabled() and img.is_cuda and self.dense_dtype == torch.float32:
+            return self._decode_heads_graphed(img, imp_condition_input)
         return self._decode_heads(img, self.dense_features(img, imp_condition_input, encoded, fork_stream))
+
+    _head_graphs = None
+
+    def enable_train_graphs(self, on=True):
+        """Training at one static view shape per GPU: the frozen UNet's forward + backward (image_branch._GraphedTaps), the frozen VAE
+        stages (gradient-free, inference kernels) and the TRAINABLE dense heads - feature projections, pixel decoder, transformer
+        decoder: forward and backward - replay as HIP graphs (train_graph.GraphedRegion; the parameters' gradients arrive through
+        their ordinary AccumulateGrad nodes, so DDP and the optimizer are unchanged).  The sparse 3D nets, the Hungarian matching
+        and the losses have data-dependent shapes and stay eager."""
+        ext = self.backbone.feature_extractor.ldm_extractor
+        ext.enable_train_graph(on)
+        ext.enable_vae_train_path(on)
+        self._head_graphs = {} if on else None
+        return self
+
+    def _decode_heads_graphed(self, img, cond):
+        from .train_graph import GraphedRegion
+
+        x = self.normalize_images(img.float())
+        feats = self.backbone.extract(x, cond)
+        size = tuple(x.shape[-2:])
+        key = (size, tuple(tuple(f.shape) for f in feats), tuple(f.requires_grad for f in feats))
+        g = self._head_graphs.get(key)
+        if g is None:
+            def region(*fs):
+                out = self.sem_seg_head({k: v.float() for k, v in self.backbone.project(list(fs), size, False).items()})
+                for k in ("pred_masks", "mask_embed", "mask_pooled_features"):
+                    out[k] = out[k].float()
+                return out
+
+            params = list(self.backbone.feature_projections.parameters()) + list(self.sem_seg_head.parameters())
+            g = self._head_graphs[key] = GraphedRegion(region, feats, params)
+        outputs = g(*feats)
+        outputs["images"] = img.float() / 255.0
+        return outputs
 
     def dense_forward(self, img, cond, encoded=None, fork_stream=None):
         """The static-shape part of the eval forward (rows a8-a17) in one call: dense_features + dense_heads.
