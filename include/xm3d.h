@@ -378,6 +378,13 @@ int xm3d_geglu(const void* x, int32_t dtype, int64_t rows, int32_t D, void* out,
  * LayerNorms of ldm's BasicTransformerBlock and open_clip's ResidualAttentionBlock (meta_arch/ldm.py:425-446, clip.py). */
 int xm3d_layer_norm(const void* x, const void* delta, int32_t dtype, int64_t rows, int32_t C, const void* gamma, const void* beta, float eps,
                     void* sum_out, void* y, void* stream);
+/* y = LayerNorm(x + delta) * gamma + beta over an f32 residual stream x (rows, C), C % 4 == 0, C <= 1024; delta f32 (delta_dtype 0) /
+ * bf16 (1) / null.  Written as any of: y (f32), y_bf = bf16(y), ypos_bf = bf16(y + pos) with pos (pos_rows, C) f32 (pos_dtype 0) / bf16 (1),
+ * stream row r reading pos row r % pos_rows.  The post-norm residual blocks of the pixel decoder's deformable-attention encoder and of the
+ * masked-attention transformer decoder under bf16 inference (/root/reference/models/modeling/pixel_decoder/msdeformattn.py:35-60,
+ * .../transformer_decoder/mask2former_transformer_decoder.py:17-178): one launch instead of cast + add + LayerNorm + add + casts. */
+int xm3d_add_layer_norm(const float* x, const void* delta, int32_t delta_dtype, int64_t rows, int32_t C, const float* gamma, const float* beta,
+                        float eps, const void* pos, int32_t pos_dtype, int64_t pos_rows, float* y, void* y_bf, void* ypos_bf, void* stream);
 /* out (B, H + pad_bottom, W + pad_right, C) <- zero-padded channels-last x (B, H, W, C); C a multiple of 4 (f32) / 8 (bf16).
  * The (0, 1, 0, 1) padding of ldm's VAE Downsample in one pass instead of F.pad's fill + strided copy. */
 int xm3d_pad_nhwc(const void* x, int32_t dtype, int64_t B, int32_t H, int32_t W, int32_t C, int32_t pad_bottom, int32_t pad_right, void* out,

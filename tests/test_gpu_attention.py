@@ -331,3 +331,25 @@ def test_attention_f32_masks_strides_and_output_views(dev):
     refd = _ref64(qd, kd, vd, mb, (E // Hd) ** -0.5)
     assert float((o.view(Lq, B, Hd, E // Hd).transpose(0, 1).double() - refd).abs().max() / refd.abs().max()) < 2e-6
     assert not ops.attention_f32_supported(torch.zeros(1, 4, 2, 80, device=dev), torch.zeros(1, 4, 2, 80, device=dev), torch.zeros(1, 4, 2, 80, device=dev))
+
+
+@pytest.mark.parametrize("rows,C,prow,ddt,pdt", [(1000, 256, 1000, torch.bfloat16, torch.float32), (5376 * 2, 256, 5376, torch.float32, torch.bfloat16),
+                                                 (7, 1024, 7, torch.bfloat16, torch.bfloat16), (33, 64, 11, None, torch.float32)])
+def test_add_layer_norm_matches_the_torch_chain(dev, rows, C, prow, ddt, pdt):
+    """xm3d_add_layer_norm == LayerNorm(x + delta.float()) in f32, its bf16 rounding, and bf16(y + pos) with pos rows repeating along the stream"""
+    import torch.nn.functional as F
+    from xmask3d_amd import ops
+
+    g = torch.Generator(device="cpu").manual_seed(rows + C)
+    x = torch.randn(rows, C, generator=g).to(dev)
+    d = None if ddt is None else torch.randn(rows, C, generator=g).to(dev, ddt)
+    pos = torch.randn(prow, C, generator=g).to(dev, pdt)
+    w, b = torch.randn(C, generator=g).to(dev), torch.randn(C, generator=g).to(dev)
+    s = x if d is None else x + d.float()
+    want = F.layer_norm(s, (C,), w, b, 1e-5)
+    y, yb, yp = ops.add_layer_norm(x, d, w, b, 1e-5, pos=pos, want=("f32", "bf16", "pos"))
+    assert (y - want).abs().max().item() <= 2e-5 * max(1.0, want.abs().max().item())
+    assert torch.equal(yb, y.to(torch.bfloat16))
+    assert torch.equal(yp, (y.view(rows // prow, prow, C) + pos.float()).view(rows, C).to(torch.bfloat16))
+    only = ops.add_layer_norm(x, d, w, b, 1e-5, want=("bf16",))
+    assert torch.equal(only, yb)

@@ -20,6 +20,8 @@ def _ref(x, w, bias, act, residual):
     elif act == "geglu":
         v, g = y.chunk(2, dim=-1)
         y = v * F.gelu(g)
+    elif act == "relu":
+        y = F.relu(y)
     if residual is not None:
         y = y + residual.float()
     return y
@@ -51,6 +53,8 @@ SHAPES = [
     (1, 64, 32, None, True, False),                    # smallest
     (255, 64, 96, None, False, True),
     (513, 960, 960, None, True, False),                # 960: 7.5 column tiles of 128
+    (5376, 256, 1024, "relu", True, False),            # deformable-attention encoder FFN: ReLU in the epilogue
+    (1000, 256, 2048, "relu", True, True),             # transformer-decoder FFN; residual added AFTER the ReLU
 ]
 
 

@@ -42,7 +42,7 @@ constexpr int GM_MT = 256;               // token rows per workgroup
 constexpr int GM_KC = 64;                // K granularity (chunks are 64 or, when K allows, 128 channels: template KC)
 constexpr int GM_D = 8;                  // weight ring depth in k-steps (= two chunks)
 
-enum { GM_ACT_NONE = 0, GM_ACT_GELU = 1, GM_ACT_QUICK_GELU = 2, GM_ACT_GEGLU = 3 };
+enum { GM_ACT_NONE = 0, GM_ACT_GELU = 1, GM_ACT_QUICK_GELU = 2, GM_ACT_GEGLU = 3, GM_ACT_RELU = 4 };  // RELU: the NONE instantiation with floor = 0
 
 struct GemmArgs {
     const __bf16* x;         // (M, K), row stride ldx elements; GF_CONV: the (B, Hin, Win, Cin) channels-last image
@@ -54,6 +54,7 @@ struct GemmArgs {
     const __bf16* wp2;       // GF_SPLIT3: the packed small-term image of W
     const float* accin;      // GF_OUT32: (M, N_out) f32, row stride ldo, added BEFORE the activation (accumulating passes), or null
     float alpha;             // GF_OUT32: the product is scaled by alpha (the power-of-two scale of a split term pair) before anything is added
+    float floor = -INFINITY;  // lower clamp after the activation, before the residual: 0 = ReLU (act code 4), -inf = none (one v_max per output)
     int M, K, N;             // N = rows of W (GEGLU: 2 N_out)
     int ldx, ldr, ldo;
     int nct;                 // column tiles
@@ -372,6 +373,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
                         if constexpr (ACT == GM_ACT_GELU) v[j] = gm_gelu(v[j]);
                         if constexpr (ACT == GM_ACT_QUICK_GELU)
                             v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[j]));
+                        if constexpr (ACT == GM_ACT_NONE) v[j] = fmaxf(v[j], a.floor);
                     }
                     if (resf) {
                         const float4 t = *reinterpret_cast<const float4*>(resf + int64_t(row) * a.ldr + col + 4 * q);
@@ -405,6 +407,7 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
                         if constexpr (ACT == GM_ACT_GELU) v[j] = gm_gelu(v[j]);
                         if constexpr (ACT == GM_ACT_QUICK_GELU)
                             v[j] = v[j] * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * v[j]));
+                        if constexpr (ACT == GM_ACT_NONE) v[j] = fmaxf(v[j], a.floor);
                     }
                     v[0] += __uint_as_float(rw[2 * q] << 16);
                     v[1] += __uint_as_float(rw[2 * q] & 0xFFFF0000u);
@@ -477,6 +480,7 @@ __global__ void k_gemm_splitk_finish(const float* __restrict__ slab, int ksplit,
         float t = v[j];
         if (act == GM_ACT_GELU) t = gm_gelu(t);
         else if (act == GM_ACT_QUICK_GELU) t = t * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-1.702f * 1.4426950408889634f * t));
+        else if (act == GM_ACT_RELU) t = fmaxf(t, 0.f);
         if (residual) t += float(r8[j]);
         o[j] = (__bf16)t;
     }
@@ -518,7 +522,9 @@ static int launch_gemm(const GemmArgs& a, int waves, int ksplit, hipStream_t s) 
 }
 
 template <int CT>
-static int dispatch_gemm(const GemmArgs& a, int act, int waves, hipStream_t s) {
+static int dispatch_gemm(const GemmArgs& a0, int act, int waves, hipStream_t s) {
+    GemmArgs a = a0;
+    if (act == GM_ACT_RELU) a.floor = 0.f, act = GM_ACT_NONE;
     switch (act) {
         case GM_ACT_NONE: return launch_gemm<CT, GM_ACT_NONE, 0>(a, waves, 1, s);
         case GM_ACT_GELU: return launch_gemm<CT, GM_ACT_GELU, 0>(a, waves, 1, s);
@@ -585,7 +591,7 @@ extern "C" int xm3d_gemm_bf16(const void* x, int64_t M, int K, int64_t ldx, cons
     XM3D_REQUIRE(K > 0 && K % GM_KC == 0, "gemm_bf16: K %d is not a multiple of %d", K, GM_KC);
     XM3D_REQUIRE(col_tile == 128 || col_tile == 256, "gemm_bf16: column tile %d unsupported", col_tile);
     XM3D_REQUIRE(N > 0 && N % 32 == 0, "gemm_bf16: N %d is not a multiple of 32", N);
-    XM3D_REQUIRE(act >= 0 && act <= 3, "gemm_bf16: unknown epilogue %d", act);
+    XM3D_REQUIRE(act >= 0 && act <= 4, "gemm_bf16: unknown epilogue %d", act);
     const int nout = act == GM_ACT_GEGLU ? N / 2 : N;
     XM3D_REQUIRE(ldx >= K && ldo >= nout && (!residual || ldr >= nout) && ldx % 8 == 0 && ldo % 8 == 0 && ldr % 8 == 0 &&
                      ldx < (int64_t(1) << 31) && ldo < (int64_t(1) << 31) && ldr < (int64_t(1) << 31),
@@ -697,8 +703,9 @@ static int gemm_f32acc_impl(const void* x, const void* x_lo, int64_t M, int32_t 
                  "gemm_f32: the one-launch form needs both planes of x and both weight images (16-byte aligned), and takes no accin");
     XM3D_REQUIRE(col_tile == 128 || col_tile == 256, "gemm_f32acc: column tile %d unsupported", col_tile);
     XM3D_REQUIRE(N > 0 && N % 32 == 0, "gemm_f32acc: N %d is not a multiple of 32", N);
-    XM3D_REQUIRE(act >= 0 && act <= 2, "gemm_f32acc: epilogue %d unsupported (none, GELU, QuickGELU)", act);
+    XM3D_REQUIRE((act >= 0 && act <= 2) || act == GM_ACT_RELU, "gemm_f32acc: epilogue %d unsupported (none, GELU, QuickGELU, ReLU)", act);
     GemmArgs a;
+    if (act == GM_ACT_RELU) a.floor = 0.f, act = GM_ACT_NONE;
     if (conv) {
         XM3D_REQUIRE(B > 0 && Hin > 0 && Win > 0 && Ho > 0 && Wo > 0 && Cin > 0 && Cin % GM_KC == 0, "gemm_f32acc: bad convolution shape (Cin %d)", Cin);
         XM3D_REQUIRE(ksize >= 1 && ksize <= 3 && stride >= 1 && pad_t >= 0 && pad_l >= 0 && pad_t < ksize && pad_l < ksize, "gemm_f32acc: kernel size 1..3, padding < kernel size");

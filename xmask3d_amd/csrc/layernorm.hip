@@ -84,6 +84,98 @@ __global__ __launch_bounds__(256) void k_layer_norm(const T* __restrict__ x, con
     }
 }
 
+// ---- residual add + LayerNorm over an f32 residual stream whose readers are bf16 GEMMs (the pixel decoder's deformable-attention encoder
+// and the masked-attention transformer decoder under bf16 inference: /root/reference/models/modeling/pixel_decoder/msdeformattn.py:35-60,
+// .../transformer_decoder/mask2former_transformer_decoder.py:17-178):
+//     y = LayerNorm(x + delta) * gamma + beta         x f32 (the stream), delta f32 / bf16 / none, statistics and y in f32
+// written as any of: y (f32, the new stream), bf16(y) (what the next linear layer's input cast would produce), bf16(y + pos) (the
+// query / key input "with positional embedding"; pos f32 or bf16, row r of the stream reads pos row r % pos_rows: a batch-broadcast
+// embedding).  One launch instead of cast + add + LayerNorm + add + two casts; the arithmetic per element is the chain's (f32 add, f32
+// LayerNorm, f32 add, one rounding to bf16).  One wave per row, C <= 1024, 16-byte accesses.
+template <typename TD, typename TP>
+__global__ __launch_bounds__(256) void k_add_layer_norm(const float* __restrict__ x, const TD* __restrict__ delta, const float* __restrict__ gamma,
+                                                        const float* __restrict__ beta, int64_t rows, int C, float eps, const TP* __restrict__ pos,
+                                                        int64_t pos_rows, float* __restrict__ y, __hip_bfloat16* __restrict__ y_bf,
+                                                        __hip_bfloat16* __restrict__ ypos_bf) {
+    constexpr int VPL = 4;  // float4 vectors per lane: C <= 64 * 4 * 4
+    const int lane = threadIdx.x & 63;
+    const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
+    if (row >= rows) return;
+    const int nv = C / 4;
+    float v[VPL][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int e = lane + 64 * i;
+        if (e < nv) {
+            const float4 t = *reinterpret_cast<const float4*>(x + row * C + e * 4);
+            v[i][0] = t.x, v[i][1] = t.y, v[i][2] = t.z, v[i][3] = t.w;
+            if (delta) {
+                if constexpr (sizeof(TD) == 4) {
+                    const float4 d = *reinterpret_cast<const float4*>(delta + row * C + e * 4);
+                    v[i][0] += d.x, v[i][1] += d.y, v[i][2] += d.z, v[i][3] += d.w;
+                } else {
+                    const uint2 d = *reinterpret_cast<const uint2*>(delta + row * C + e * 4);
+                    v[i][0] += __uint_as_float(d.x << 16), v[i][1] += __uint_as_float(d.x & 0xFFFF0000u);
+                    v[i][2] += __uint_as_float(d.y << 16), v[i][3] += __uint_as_float(d.y & 0xFFFF0000u);
+                }
+            }
+#pragma unroll
+            for (int j = 0; j < 4; ++j) s += v[i][j];
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off);
+    const float mean = s / float(C);
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        if (lane + 64 * i < nv) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float d = v[i][j] - mean;
+                ss = fmaf(d, d, ss);
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) ss += __shfl_xor(ss, off);
+    const float rstd = rsqrtf(ss / float(C) + eps);
+    const int64_t prow = pos ? row % pos_rows : 0;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+        const int e = lane + 64 * i;
+        if (e < nv) {
+            const float4 g = gamma ? *reinterpret_cast<const float4*>(gamma + e * 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+            const float4 b = beta ? *reinterpret_cast<const float4*>(beta + e * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            float o[4] = {fmaf((v[i][0] - mean) * rstd, g.x, b.x), fmaf((v[i][1] - mean) * rstd, g.y, b.y), fmaf((v[i][2] - mean) * rstd, g.z, b.z),
+                          fmaf((v[i][3] - mean) * rstd, g.w, b.w)};
+            if (y) *reinterpret_cast<float4*>(y + row * C + e * 4) = make_float4(o[0], o[1], o[2], o[3]);
+            if (y_bf) {
+                __hip_bfloat16 q[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = __float2bfloat16(o[j]);
+                *reinterpret_cast<uint2*>(y_bf + row * C + e * 4) = *reinterpret_cast<const uint2*>(q);
+            }
+            if (ypos_bf) {
+                float p[4];
+                if constexpr (sizeof(TP) == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(pos + prow * C + e * 4);
+                    p[0] = t.x, p[1] = t.y, p[2] = t.z, p[3] = t.w;
+                } else {
+                    const uint2 t = *reinterpret_cast<const uint2*>(pos + prow * C + e * 4);
+                    p[0] = __uint_as_float(t.x << 16), p[1] = __uint_as_float(t.x & 0xFFFF0000u);
+                    p[2] = __uint_as_float(t.y << 16), p[3] = __uint_as_float(t.y & 0xFFFF0000u);
+                }
+                __hip_bfloat16 q[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) q[j] = __float2bfloat16(o[j] + p[j]);
+                *reinterpret_cast<uint2*>(ypos_bf + row * C + e * 4) = *reinterpret_cast<const uint2*>(q);
+            }
+        }
+    }
+}
+
 }  // namespace xm3d
 
 using namespace xm3d;
@@ -111,6 +203,35 @@ extern "C" int xm3d_layer_norm(const void* x, const void* delta, int32_t dtype, 
                            static_cast<const __hip_bfloat16*>(delta), static_cast<const __hip_bfloat16*>(gamma),
                            static_cast<const __hip_bfloat16*>(beta), rows, C, eps, static_cast<__hip_bfloat16*>(sum_out),
                            static_cast<__hip_bfloat16*>(y));
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}
+
+// delta_dtype / pos_dtype: 0 = f32, 1 = bf16 (ignored when the pointer is null).  Any of y / y_bf / ypos_bf may be null (not all); ypos_bf needs pos.
+extern "C" int xm3d_add_layer_norm(const float* x, const void* delta, int32_t delta_dtype, int64_t rows, int32_t C, const float* gamma, const float* beta,
+                                   float eps, const void* pos, int32_t pos_dtype, int64_t pos_rows, float* y, void* y_bf, void* ypos_bf, void* stream) {
+    XM3D_REQUIRE(rows >= 0 && C >= 4 && C % 4 == 0 && C <= 1024, "add_layer_norm: rows=%lld, C=%d (multiple of 4, <= 1024) expected", (long long)rows, C);
+    if (rows == 0) return XM3D_OK;
+    XM3D_REQUIRE(x && (y || y_bf || ypos_bf), "add_layer_norm: null pointer");
+    XM3D_REQUIRE((delta_dtype == 0 || delta_dtype == 1) && (pos_dtype == 0 || pos_dtype == 1), "add_layer_norm: dtype codes are 0 (f32) / 1 (bf16)");
+    XM3D_REQUIRE(!ypos_bf || (pos && pos_rows > 0), "add_layer_norm: ypos_bf needs pos and pos_rows > 0");
+    XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0 &&
+                     ((reinterpret_cast<uintptr_t>(delta) | reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(y_bf) | reinterpret_cast<uintptr_t>(ypos_bf)) & 7) == 0,
+                 "add_layer_norm: f32 tensors must be 16-byte aligned, bf16 tensors 8-byte aligned");
+    hipStream_t s = as_stream(stream);
+    const unsigned blocks = unsigned((rows + 3) / 4);
+    typedef __hip_bfloat16 bf;
+#define XM3D_ALN(TD, TP)                                                                                                                            \
+    hipLaunchKernelGGL((k_add_layer_norm<TD, TP>), dim3(blocks), dim3(256), 0, s, x, static_cast<const TD*>(delta), gamma, beta, rows, C, eps,   \
+                       static_cast<const TP*>(pos), pos_rows, y, static_cast<bf*>(y_bf), static_cast<bf*>(ypos_bf))
+    if (delta_dtype == 0) {
+        if (pos_dtype == 0) XM3D_ALN(float, float);
+        else XM3D_ALN(float, bf);
+    } else {
+        if (pos_dtype == 0) XM3D_ALN(bf, float);
+        else XM3D_ALN(bf, bf);
+    }
+#undef XM3D_ALN
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }

@@ -38,6 +38,21 @@ class PositionEmbeddingSine(nn.Module):
     def forward(self, x, mask=None):
         b, _, h, w = x.shape
         dev = x.device
+        if mask is None and x.is_cuda:
+            # no padding mask: the embedding depends on (h, w) only - computed once per shape and device (12 launches per call before:
+            # ~0.35 ms of every forward), handed out as a batch-broadcast view.  Not cached from inside a graph capture (the tensor
+            # would live in the capture's pool).
+            key = (h, w, str(dev))
+            cache = self.__dict__.setdefault("_pe_cache", {})
+            pe = cache.get(key)
+            if pe is None:
+                pe = self._compute(1, h, w, dev, None)
+                if not torch.cuda.is_current_stream_capturing():
+                    cache[key] = pe
+            return pe.expand(b, -1, -1, -1)
+        return self._compute(b, h, w, dev, mask)
+
+    def _compute(self, b, h, w, dev, mask):
         if mask is None:
             y_embed = torch.arange(1, h + 1, dtype=torch.float32, device=dev).view(1, h, 1).expand(b, h, w)
             x_embed = torch.arange(1, w + 1, dtype=torch.float32, device=dev).view(1, 1, w).expand(b, h, w)
@@ -58,6 +73,18 @@ class PositionEmbeddingSine(nn.Module):
         return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
 
 
+def _bf16_stream_ok(x):
+    """bf16 inference (autocast region of XMASK3d._decode_heads) over an f32 residual stream: the post-norm blocks below then run as
+    bf16 GEMMs (flinear) + ONE fused residual-add + LayerNorm launch per block (ops.add_layer_norm) that also emits the bf16 copies the
+    next GEMMs read - instead of cast + add + LayerNorm + add + casts.  The stream travels as (f32, bf16, bf16 of stream + pos)."""
+    return (x.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
+            and ops.add_layer_norm_supported(x, x.shape[-1]) and os.environ.get("XM3D_FUSED_LN", "hip") != "library")
+
+
+def _add_ln(norm, x32, delta, pos=None, want=("f32", "bf16")):
+    return ops.add_layer_norm(x32, delta, norm.weight.float(), norm.bias.float(), norm.eps, pos=pos, want=want)
+
+
 # ----------------------------------------------------------------------------- pixel decoder
 class MSDeformAttnTransformerEncoderLayer(nn.Module):
     def __init__(self, d_model=256, d_ffn=1024, dropout=0.1, n_levels=4, n_heads=8, n_points=4):
@@ -74,8 +101,17 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask)
         src = self.norm1(src + self.dropout1(src2))
-        src2 = self.linear2(self.dropout2(F.relu(self.linear1(src))))
+        src2 = self.linear2(self.dropout2(flinear(src, self.linear1.weight, self.linear1.bias, act="relu")))
         return self.norm2(src + self.dropout3(src2))
+
+    def forward_stream(self, st, pos, reference_points, spatial_shapes, level_start_index):
+        """bf16 inference on the (f32, bf16, bf16 + pos) stream: same arithmetic, 2 fused add + LayerNorm launches per layer"""
+        src32, src_b, srcpos_b = st
+        delta = self.self_attn(srcpos_b, reference_points, src_b, spatial_shapes, level_start_index, None)
+        src32, src_b = _add_ln(self.norm1, src32, delta.contiguous())
+        h = flinear(src_b, self.linear1.weight, self.linear1.bias, act="relu")
+        delta = flinear(h, self.linear2.weight, self.linear2.bias)
+        return _add_ln(self.norm2, src32, delta.contiguous(), pos=pos, want=("f32", "bf16", "pos"))
 
 
 class MSDeformAttnTransformerEncoder(nn.Module):
@@ -99,6 +135,13 @@ class MSDeformAttnTransformerEncoder(nn.Module):
     def forward(self, src, spatial_shapes_list, spatial_shapes, level_start_index, valid_ratios, pos):
         ref = self.get_reference_points(spatial_shapes_list, valid_ratios, src.device)
         out = src
+        src32 = src.float().contiguous() if (src.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled("cuda")) else None
+        if src32 is not None and _bf16_stream_ok(src32) and pos.shape == src.shape and all(l.linear1.weight.dtype == torch.bfloat16 for l in self.layers):
+            pos = pos.contiguous()
+            st = (src32, src32.to(torch.bfloat16), (src32 + pos).to(torch.bfloat16))
+            for layer in self.layers:
+                st = layer.forward_stream(st, pos, ref, spatial_shapes, level_start_index)
+            return st[0]
         for layer in self.layers:
             out = layer(out, pos, ref, spatial_shapes, level_start_index, None)
         return out
@@ -299,6 +342,25 @@ class SelfAttentionLayer(nn.Module):
                 return self.norm(tgt + flinear(o, mha.out_proj.weight, mha.out_proj.bias))
         return self.norm(tgt + self.self_attn(q, k, value=tgt, need_weights=False)[0])
 
+    def forward_stream(self, st, query_pos):
+        """bf16 inference on the (f32, bf16, bf16 + query_pos) stream; None when the flash-attention kernel does not take the shapes"""
+        tgt32, tgt_b, tgtpos_b = st
+        mha = self.self_attn
+        E, H = mha.embed_dim, mha.num_heads
+        w, b = mha.in_proj_weight, mha.in_proj_bias
+        L, B = tgt_b.shape[:2]
+        qk = flinear(tgtpos_b, w[: 2 * E], b[: 2 * E])
+        v = flinear(tgt_b, w[2 * E:], b[2 * E:])
+        q4 = qk[..., :E].unflatten(-1, (H, E // H)).transpose(0, 1)
+        k4 = qk[..., E:].unflatten(-1, (H, E // H)).transpose(0, 1)
+        v4 = v.view(L, B, H, E // H).transpose(0, 1)
+        if not ops.attention_supported(q4, k4, v4):
+            return None
+        o = torch.empty((L, B, E), dtype=q4.dtype, device=tgt_b.device)
+        ops.attention(q4, k4, v4, out=o.view(L, B, H, E // H).transpose(0, 1))
+        delta = flinear(o, mha.out_proj.weight, mha.out_proj.bias)
+        return _add_ln(self.norm, tgt32, delta, pos=query_pos, want=("f32", "bf16", "pos"))
+
 
 class CrossAttentionLayer(nn.Module):
     def __init__(self, d_model, nhead, dropout=0.0):
@@ -344,6 +406,26 @@ class CrossAttentionLayer(nn.Module):
         tgt2 = flinear(o.permute(2, 0, 1, 3).reshape(Lq, B, E), mha.out_proj.weight, mha.out_proj.bias)
         return self.norm(tgt + tgt2)
 
+    def forward_stream(self, st, memory_b, key_b, memory_bias, query_pos):
+        """bf16 inference on the (f32, bf16, bf16 + query_pos) stream; memory_b / key_b: contiguous bf16 (Lk, B, E) copies of the level's
+        memory and memory + pos (made once per level, three layers read each).  None when the flash-attention kernel does not apply."""
+        tgt32, tgt_b, tgtpos_b = st
+        mha = self.multihead_attn
+        E, H = mha.embed_dim, mha.num_heads
+        w, b = mha.in_proj_weight, mha.in_proj_bias
+        q = flinear(tgtpos_b, w[:E], b[:E])
+        k = flinear(key_b, w[E:2 * E], b[E:2 * E])
+        v = flinear(memory_b, w[2 * E:], b[2 * E:])
+        Lq, B = q.shape[:2]
+        Lk = k.shape[0]
+        q4, k4, v4 = (t.view(t.shape[0], B, H, E // H).transpose(0, 1) for t in (q, k, v))
+        if not ops.attention_supported(q4, k4, v4):
+            return None
+        o = torch.empty((Lq, B, E), dtype=q.dtype, device=q.device)
+        ops.attention(q4, k4, v4, bias=memory_bias.view(B, 1, Lq, Lk), out=o.view(Lq, B, H, E // H).transpose(0, 1))
+        delta = flinear(o, mha.out_proj.weight, mha.out_proj.bias)
+        return _add_ln(self.norm, tgt32, delta, pos=query_pos, want=("f32", "bf16", "pos"))
+
 
 class FFNLayer(nn.Module):
     def __init__(self, d_model, dim_feedforward=2048):
@@ -356,7 +438,13 @@ class FFNLayer(nn.Module):
                 nn.init.xavier_uniform_(p)
 
     def forward(self, tgt):
-        return self.norm(tgt + self.linear2(F.relu(self.linear1(tgt))).float())
+        return self.norm(tgt + self.linear2(flinear(tgt, self.linear1.weight, self.linear1.bias, act="relu")).float())
+
+    def forward_stream(self, st, query_pos):
+        tgt32, tgt_b, _ = st
+        h = flinear(tgt_b, self.linear1.weight, self.linear1.bias, act="relu")
+        delta = flinear(h, self.linear2.weight, self.linear2.bias)
+        return _add_ln(self.norm, tgt32, delta, pos=query_pos, want=("f32", "bf16", "pos"))
 
 
 class MLP(nn.Module):
@@ -367,8 +455,8 @@ class MLP(nn.Module):
         self.layers = nn.ModuleList(Linear(n, k) for n, k in zip([input_dim] + h, h + [output_dim]))
 
     def forward(self, x):
-        for i, layer in enumerate(self.layers):
-            x = F.relu(layer(x)) if i < self.num_layers - 1 else layer(x)
+        for i, layer in enumerate(self.layers):  # (the ReLU rides in the GEMM epilogue where the own kernel runs)
+            x = flinear(x, layer.weight, layer.bias, act="relu") if i < self.num_layers - 1 else layer(x)
         return x
 
 
@@ -487,8 +575,26 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
         skip = self.prune_aux_embed and not self.training
         c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[0], not skip)
         cls_l.append(c), mask_l.append(m), extra_l.append(e)
+        st = mem_b = key_b = None
+        if attn_mask.dtype != torch.bool and _bf16_stream_ok(output) and self.transformer_ffn_layers[0].linear1.weight.dtype == torch.bfloat16:
+            query_embed = query_embed.contiguous()
+            st = (output, output.to(torch.bfloat16), (output + query_embed).to(torch.bfloat16))
+            mem_b = [s_.to(torch.bfloat16).contiguous() for s_ in src]    # once per level: three layers read each
+            key_b = [k_.to(torch.bfloat16).contiguous() for k_ in keys]
         for i in range(self.num_layers):
             lvl = i % self.num_feature_levels
+            if st is not None and attn_mask.dtype != torch.bool:
+                # bf16 inference: the layer triple on the (f32, bf16, bf16 + query_pos) stream - one fused add + LayerNorm per block
+                s1 = self.transformer_cross_attention_layers[i].forward_stream(st, mem_b[lvl], key_b[lvl], attn_mask, query_embed)
+                s2 = self.transformer_self_attention_layers[i].forward_stream(s1, query_embed) if s1 is not None else None
+                if s2 is not None:
+                    st = self.transformer_ffn_layers[i].forward_stream(s2, query_embed)
+                    output = st[0]
+                    c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[(i + 1) % self.num_feature_levels],
+                                                                       not skip or i == self.num_layers - 1)
+                    cls_l.append(c), mask_l.append(m), extra_l.append(e)
+                    continue
+                st = None  # a shape the kernels do not take: the plain path from here on
             if attn_mask.dtype == torch.bool:
                 # a query whose mask is empty everywhere attends to everything (odise.py:395)
                 full = attn_mask.all(dim=-1, keepdim=True)
@@ -513,10 +619,15 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
         return out
 
     def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, with_embed=True):
-        decoder_output = self.decoder_norm(output).transpose(0, 1)
+        if _bf16_stream_ok(output) and self.mask_embed.layers[0].weight.dtype == torch.bfloat16:
+            # bf16 inference: the fused LayerNorm hands the f32 rows (pooled-embedding residual) and their bf16 copy (the GEMMs' input)
+            dec32, dec_b = _add_ln(self.decoder_norm, output, None)
+            decoder_output, dec_in = dec32.transpose(0, 1), dec_b.transpose(0, 1).contiguous()
+        else:
+            decoder_output = dec_in = self.decoder_norm(output).transpose(0, 1)
         # (the class logits of a layer whose pooled embedding is pruned feed nothing either: same switch)
-        outputs_class = self.class_embed(decoder_output) if with_embed else None
-        mask_embed = self.mask_embed(decoder_output)
+        outputs_class = self.class_embed(dec_in) if with_embed else None
+        mask_embed = self.mask_embed(dec_in)
         extra = {}
         if mask_embed.is_cuda and not torch.is_grad_enabled() and os.environ.get("XM3D_MASK_HEADS", "hip") != "library":
             from . import ops

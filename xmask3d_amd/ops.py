@@ -638,7 +638,7 @@ def conv3x3_f32(x, packs, cout, tile, bias=None, gn=None, residual=None, stats_g
 
 
 # ---- linear layer / 1x1 convolution with fused epilogue (csrc/gemm.hip)
-GEMM_ACTS = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "geglu": 3}
+GEMM_ACTS = {None: 0, "none": 0, "gelu": 1, "quick_gelu": 2, "geglu": 3, "relu": 4}
 
 
 def gemm_supported(x, n_rows, k=None):
@@ -674,7 +674,8 @@ def gemm_pack_weight(weight, act=None):
     w = w.contiguous()
     tile = lib().xm3d_gemm_col_tile(n)
     packed = torch.empty(lib().xm3d_gemm_packed_elems(n, k, tile), dtype=torch.bfloat16, device=w.device)
-    check(lib().xm3d_gemm_pack_weight(_ptr(w), int(w.dtype == torch.float32), n, k, GEMM_ACTS[act], tile, _ptr(packed), _stream()), "xm3d_gemm_pack_weight")
+    check(lib().xm3d_gemm_pack_weight(_ptr(w), int(w.dtype == torch.float32), n, k, 3 if act == "geglu" else 0, tile, _ptr(packed), _stream()),
+          "xm3d_gemm_pack_weight")
     return packed, tile
 
 
@@ -1082,6 +1083,42 @@ def layer_norm(x, weight, bias, eps=1e-5, delta=None, want_sum=False):
     check(lib().xm3d_layer_norm(_ptr(x), _ptr(delta), 0 if x.dtype == torch.float32 else 1, x.numel() // C, C, _ptr(weight), _ptr(bias),
                                 float(eps), _ptr(s), _ptr(y), _stream()), "xm3d_layer_norm")
     return (y, s) if want_sum else y
+
+
+def add_layer_norm_supported(x, C):
+    """inference on an f32 residual stream xm3d_add_layer_norm takes as it is"""
+    return (not torch.is_grad_enabled() and x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and x.shape[-1] == C and C % 4 == 0
+            and C <= 1024)
+
+
+def add_layer_norm(x, delta, weight, bias, eps=1e-5, pos=None, want=("f32", "bf16")):
+    """LayerNorm(x + delta) over the last dimension of the contiguous f32 stream x; delta f32 / bf16 like x, or None; weight / bias f32.
+    want: which forms to return, in order - "f32" (the new stream), "bf16" (its bf16 rounding), "pos" (bf16(y + pos); pos f32 / bf16
+    whose rows repeat along the rows of x: the trailing rows.numel / C rows of x line up with pos)."""
+    C = x.shape[-1]
+    if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and C <= 1024):
+        raise TypeError("add_layer_norm: contiguous f32 device tensor with C % 4 == 0, C <= 1024 required")
+    if delta is not None and (delta.shape != x.shape or not delta.is_contiguous() or delta.dtype not in (torch.float32, torch.bfloat16)):
+        raise TypeError("add_layer_norm: delta must be a contiguous f32 / bf16 tensor of the shape of x")
+    for t in (weight, bias):
+        if t is not None and (t.dtype != torch.float32 or not t.is_contiguous() or t.numel() != C):
+            raise TypeError("add_layer_norm: weight / bias must be contiguous f32 (C,) tensors")
+    rows = x.numel() // C
+    prow = 0
+    if "pos" in want:
+        if pos is None or pos.shape[-1] != C or not pos.is_contiguous() or pos.dtype not in (torch.float32, torch.bfloat16):
+            raise TypeError("add_layer_norm: pos must be a contiguous f32 / bf16 (..., C) tensor")
+        prow = pos.numel() // C
+        if prow == 0 or rows % prow:
+            raise TypeError("add_layer_norm: the rows of pos must tile the rows of x")
+    outs = {"f32": torch.empty_like(x) if "f32" in want else None,
+            "bf16": torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if "bf16" in want else None,
+            "pos": torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if "pos" in want else None}
+    check(lib().xm3d_add_layer_norm(_ptr(x), _ptr(delta), int(delta is not None and delta.dtype == torch.bfloat16), rows, C, _ptr(weight), _ptr(bias),
+                                    float(eps), _ptr(pos) if "pos" in want else None, int(pos is not None and pos.dtype == torch.bfloat16), prow,
+                                    _ptr(outs["f32"]), _ptr(outs["bf16"]), _ptr(outs["pos"]), _stream()), "xm3d_add_layer_norm")
+    res = tuple(outs[k] for k in want)
+    return res[0] if len(res) == 1 else res
 
 
 def pad_bottom_right_nhwc(x, pad_bottom, pad_right):

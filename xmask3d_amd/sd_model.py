@@ -384,6 +384,8 @@ def flinear(x, weight, bias=None, act=None, residual=None):
         y = y * torch.sigmoid(1.702 * y)
     elif act == "gelu":
         y = F.gelu(y)
+    elif act == "relu":
+        y = F.relu(y)
     return y if residual is None else y + residual
 
 

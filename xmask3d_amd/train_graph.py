@@ -50,9 +50,11 @@ class GraphedNoGrad:
 class GraphedRegion:
     def __init__(self, fn, inputs, params, warmup=3):
         self.params = tuple(p for p in params if p.requires_grad)
-        # the parameters' AccumulateGrad nodes are made HERE, on the caller's stream (where the eager backward delivers their gradients):
-        # made lazily inside the warm-up they would belong to the private stream and every later backward would cross streams
-        self._acc = [p.expand_as(p).grad_fn.next_functions[0][0] for p in self.params]
+        # The parameters' AccumulateGrad nodes come into being inside the warm-up, on the private stream, and stay alive with the captured
+        # autograd graph.  That is on purpose: made on the caller's (legacy) stream instead, the engine orders that stream against the
+        # capturing one INSIDE the backward capture, and the replay of such a graph ends in a segmentation fault in hipGraphLaunch.  The
+        # price is that the eager backward hands the parameter gradients across streams (the engine synchronises them; torch warns once).
+        torch.autograd.graph.set_warn_on_accumulate_grad_stream_mismatch(False)
         self.stream = torch.cuda.Stream()
         self.stream.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(self.stream):

@@ -216,7 +216,8 @@ class XMASK3d(nn.Module):
         # bf16 mode: GEMMs of the pixel / transformer decoder run in bf16 too (the reference keeps them fp32; sampling in
         # xm3d_msda_forward, LayerNorm statistics and the mask logits stay f32)
         with torch.autocast(device_type=img.device.type, dtype=torch.bfloat16, enabled=low):
-            outputs = self.sem_seg_head({k: v.float() for k, v in feature.items()})
+            # (low: the projected features are bf16 and every consumer runs under autocast - an f32 copy would be cast straight back)
+            outputs = self.sem_seg_head(feature if low else {k: v.float() for k, v in feature.items()})
         for k in ("pred_masks", "mask_embed", "mask_pooled_features"):
             outputs[k] = outputs[k].float()
         outputs["images"] = img.float() / 255.0
