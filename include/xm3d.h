@@ -385,6 +385,21 @@ int xm3d_layer_norm(const void* x, const void* delta, int32_t dtype, int64_t row
  * .../transformer_decoder/mask2former_transformer_decoder.py:17-178): one launch instead of cast + add + LayerNorm + add + casts. */
 int xm3d_add_layer_norm(const float* x, const void* delta, int32_t delta_dtype, int64_t rows, int32_t C, const float* gamma, const float* beta,
                         float eps, const void* pos, int32_t pos_dtype, int64_t pos_rows, float* y, void* y_bf, void* ypos_bf, void* stream);
+/* Backward of LayerNorm over (rows, C) f32, C % 4 == 0, C <= 2048 (<= 1024 with parameter gradients): dx from x, dy, gamma (f32 or null) - the
+ * row statistics are recomputed, nothing but x is kept from the forward.  dgamma / dbeta (C) or null; with either, ws =
+ * xm3d_layer_norm_bwd_ws_floats(rows, C) floats of scratch (per-workgroup partial rows, added in index order: no atomics, bit-reproducible).
+ * Replaces torch's layer_norm backward under /root/reference/run/train.py:504-540 (nn.LayerNorm of mask2former_transformer_decoder.py:17-178,
+ * msdeformattn.py:35-60, the frozen UNet's BasicTransformerBlock norms, meta_arch/ldm.py:425-446). */
+int64_t xm3d_layer_norm_bwd_ws_floats(int64_t rows, int32_t C);
+int xm3d_layer_norm_bwd(const float* x, const float* dy, const float* gamma, int64_t rows, int32_t C, float eps, float* dx, float* dgamma, float* dbeta,
+                        float* ws, void* stream);
+/* Backward of xm3d_group_norm (NCHW f32, (B, C, hw) contiguous, hw % 4 == 0, B * C <= 65535) INCLUDING its fused activation (act 0 none / 1
+ * SiLU / 2 ReLU): dx from x, dy, the forward's moments (`stats_ws` of xm3d_group_norm: sum and sum of squares per (sample, group), f64), gamma /
+ * beta (f32 (C) or null).  dgamma / dbeta (C) or null (frozen norms).  ws: xm3d_group_norm_bwd_ws_floats(B, C, G) floats.  All sums in a
+ * fixed order.  nn.GroupNorm of backbone/feature_extractor.py:40-47, msdeformattn.py and the UNet's ResBlocks under run/train.py:504-540. */
+int64_t xm3d_group_norm_bwd_ws_floats(int64_t B, int32_t C, int32_t G);
+int xm3d_group_norm_bwd(const float* x, const float* dy, const double* stats, const float* gamma, const float* beta, int64_t B, int32_t C, int32_t hw,
+                        int32_t G, float eps, int32_t act, float* dx, float* dgamma, float* dbeta, float* ws, void* stream);
 /* out (B, H + pad_bottom, W + pad_right, C) <- zero-padded channels-last x (B, H, W, C); C a multiple of 4 (f32) / 8 (bf16).
  * The (0, 1, 0, 1) padding of ldm's VAE Downsample in one pass instead of F.pad's fill + strided copy. */
 int xm3d_pad_nhwc(const void* x, int32_t dtype, int64_t B, int32_t H, int32_t W, int32_t C, int32_t pad_bottom, int32_t pad_right, void* out,

@@ -25,7 +25,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .sd_model import ACT_NONE, ACT_RELU, AutoencoderKL, UNetModel, _gn_f32, _packed, _packed_split, fused_conv_ok, gn_act, own_conv
+from .sd_model import ACT_NONE, ACT_RELU, AutoencoderKL, GroupNorm, UNetModel, _gn_f32, _packed, _packed_split, fused_conv_ok, gn_act, own_conv
 
 SCALE_FACTOR = 0.18215
 # sqrt(alphas_cumprod[0]) and sqrt(1 - alphas_cumprod[0]) of the "ldm_linear" schedule
@@ -343,7 +343,7 @@ class _ConvGN(nn.Conv2d):
 
     def __init__(self, cin, cout, k, padding=0, relu=False):
         super().__init__(cin, cout, k, padding=padding, bias=False)
-        self.norm = nn.GroupNorm(32, cout)
+        self.norm = GroupNorm(32, cout)
         self._relu = relu
 
     def forward(self, x, residual=None, relu=None):

@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from .sd_model import ACT_NONE, ACT_RELU, Conv2d, Linear, flinear, fused_conv_ok, gn_act, own_conv, plain_conv3x3
+from .sd_model import ACT_NONE, ACT_RELU, Conv2d, GroupNorm, LayerNorm, Linear, flinear, fused_conv_ok, gn_act, own_conv, plain_conv3x3
 from .msda import MSDeformAttn
 
 
@@ -91,12 +91,12 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         super().__init__()
         self.self_attn = MSDeformAttn(d_model, n_levels, n_heads, n_points)
         self.dropout1 = nn.Dropout(dropout)
-        self.norm1 = nn.LayerNorm(d_model)
+        self.norm1 = LayerNorm(d_model)
         self.linear1 = Linear(d_model, d_ffn)
         self.dropout2 = nn.Dropout(dropout)
         self.linear2 = Linear(d_ffn, d_model)
         self.dropout3 = nn.Dropout(dropout)
-        self.norm2 = nn.LayerNorm(d_model)
+        self.norm2 = LayerNorm(d_model)
 
     def forward(self, src, pos, reference_points, spatial_shapes, level_start_index, padding_mask=None):
         src2 = self.self_attn(src + pos, reference_points, src, spatial_shapes, level_start_index, padding_mask)
@@ -189,7 +189,7 @@ class _Conv(nn.Conv2d):
     def __init__(self, cin, cout, k, padding=0, bias=True, gn=False, relu=False):
         super().__init__(cin, cout, k, padding=padding, bias=bias)
         if gn:
-            self.norm = nn.GroupNorm(32, cout)
+            self.norm = GroupNorm(32, cout)
         self._gn, self._relu = gn, relu
 
     def _conv(self, x):
@@ -251,7 +251,7 @@ class MSDeformAttnPixelDecoder(nn.Module):
         self.transformer_feature_strides = [v[1] for _, v in titems]
         self.transformer_num_feature_levels = len(titems)
         self.input_proj = nn.ModuleList(
-            nn.Sequential(Conv2d(v[0], conv_dim, kernel_size=1), nn.GroupNorm(32, conv_dim)) for _, v in titems[::-1])
+            nn.Sequential(Conv2d(v[0], conv_dim, kernel_size=1), GroupNorm(32, conv_dim)) for _, v in titems[::-1])
         for proj in self.input_proj:
             nn.init.xavier_uniform_(proj[0].weight, gain=1)
             nn.init.constant_(proj[0].bias, 0)
@@ -313,7 +313,7 @@ class SelfAttentionLayer(nn.Module):
     def __init__(self, d_model, nhead, dropout=0.0):
         super().__init__()
         self.self_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = LayerNorm(d_model)
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
@@ -366,7 +366,7 @@ class CrossAttentionLayer(nn.Module):
     def __init__(self, d_model, nhead, dropout=0.0):
         super().__init__()
         self.multihead_attn = nn.MultiheadAttention(d_model, nhead, dropout=dropout)
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = LayerNorm(d_model)
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
@@ -432,7 +432,7 @@ class FFNLayer(nn.Module):
         super().__init__()
         self.linear1 = Linear(d_model, dim_feedforward)
         self.linear2 = Linear(dim_feedforward, d_model)
-        self.norm = nn.LayerNorm(d_model)
+        self.norm = LayerNorm(d_model)
         for p in self.parameters():
             if p.dim() > 1:
                 nn.init.xavier_uniform_(p)
@@ -494,8 +494,8 @@ class MaskPooling(nn.Module):
 class PooledMaskEmbed(nn.Module):
     def __init__(self, hidden_dim, mask_dim, projection_dim, temperature=0.07):
         super().__init__()
-        self.pool_proj = nn.Sequential(nn.LayerNorm(hidden_dim), Linear(hidden_dim, hidden_dim))
-        self.mask_embed = nn.Sequential(nn.LayerNorm(mask_dim), MLP(mask_dim, hidden_dim, projection_dim, 3))
+        self.pool_proj = nn.Sequential(LayerNorm(hidden_dim), Linear(hidden_dim, hidden_dim))
+        self.mask_embed = nn.Sequential(LayerNorm(mask_dim), MLP(mask_dim, hidden_dim, projection_dim, 3))
         self.logit_scale = nn.Parameter(torch.ones([]) * np.log(1 / temperature))
         self.mask_pooling = MaskPooling()
 
@@ -539,7 +539,7 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
         self.transformer_self_attention_layers = nn.ModuleList(SelfAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
         self.transformer_cross_attention_layers = nn.ModuleList(CrossAttentionLayer(hidden_dim, nheads) for _ in range(dec_layers))
         self.transformer_ffn_layers = nn.ModuleList(FFNLayer(hidden_dim, dim_feedforward) for _ in range(dec_layers))
-        self.decoder_norm = nn.LayerNorm(hidden_dim)
+        self.decoder_norm = LayerNorm(hidden_dim)
         self.num_queries = num_queries
         self.query_feat = nn.Embedding(num_queries, hidden_dim)
         self.query_embed = nn.Embedding(num_queries, hidden_dim)

@@ -471,6 +471,43 @@ def group_norm(x, num_groups, weight=None, bias=None, eps=1e-5, silu=False, shif
     return y if residual is None else _act_torch(y + residual, silu)
 
 
+def group_norm_nchw_stats(x, num_groups, weight, bias, eps, act):
+    """training forward: xm3d_group_norm on a contiguous (B, C, ...) f32 tensor -> (act(GroupNorm(x)), the moments buffer its backward reads)"""
+    B, C = x.shape[0], x.shape[1]
+    hw = x.numel() // max(B * C, 1)
+    y = torch.empty_like(x)
+    stats = torch.empty(lib().xm3d_gn_stats_doubles_nchw(B, C, hw, num_groups), dtype=torch.float64, device=x.device)
+    check(lib().xm3d_group_norm(_ptr(x), 0, B, C, hw, num_groups, _ptr(weight), _ptr(bias), float(eps), int(act), _ptr(y), _ptr(stats), _stream()),
+          "xm3d_group_norm")
+    return y, stats
+
+
+def group_norm_bwd(x, dy, stats, num_groups, weight, bias, eps, act, need_affine):
+    """-> (dx, dgamma | None, dbeta | None) of act(GroupNorm(x)) for contiguous (B, C, ...) f32 tensors (xm3d_group_norm_bwd)"""
+    B, C = x.shape[0], x.shape[1]
+    hw = x.numel() // max(B * C, 1)
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device) if need_affine else None
+    db = torch.empty(C, dtype=torch.float32, device=x.device) if need_affine else None
+    ws = torch.empty(lib().xm3d_group_norm_bwd_ws_floats(B, C, num_groups), dtype=torch.float32, device=x.device)
+    check(lib().xm3d_group_norm_bwd(_ptr(x), _ptr(dy), _ptr(stats), _ptr(weight), _ptr(bias), B, C, hw, num_groups, float(eps), int(act), _ptr(dx), _ptr(dg),
+                                    _ptr(db), _ptr(ws), _stream()), "xm3d_group_norm_bwd")
+    return dx, dg, db
+
+
+def layer_norm_bwd(x, dy, weight, eps, need_affine):
+    """-> (dx, dgamma | None, dbeta | None) of LayerNorm over the last dimension of contiguous f32 tensors (xm3d_layer_norm_bwd)"""
+    C = x.shape[-1]
+    rows = x.numel() // C
+    dx = torch.empty_like(x)
+    dg = torch.empty(C, dtype=torch.float32, device=x.device) if need_affine else None
+    db = torch.empty(C, dtype=torch.float32, device=x.device) if need_affine else None
+    ws = torch.empty(lib().xm3d_layer_norm_bwd_ws_floats(rows, C), dtype=torch.float32, device=x.device) if need_affine else None
+    check(lib().xm3d_layer_norm_bwd(_ptr(x), _ptr(dy), _ptr(weight), rows, C, float(eps), _ptr(dx), _ptr(dg), _ptr(db), _ptr(ws), _stream()),
+          "xm3d_layer_norm_bwd")
+    return dx, dg, db
+
+
 def bias_residual(a, b, bias, stats_groups=None):
     """out = a + b + bias[c] for channels-last (B,C,H,W) f32/bf16 device tensors; a may be None.
     stats_groups: G of the GroupNorm expected to read the result (its statistics are then computed here, on the way)."""

@@ -33,8 +33,30 @@ def swish(x):
     return x * torch.sigmoid(x)
 
 
+class LayerNorm(nn.LayerNorm):
+    """nn.LayerNorm whose f32 training forward / backward run on the HIP kernels (norm_train.LayerNormFn); torch otherwise"""
+
+    def forward(self, x):
+        from . import norm_train
+
+        if norm_train.layer_norm_ok(x, self.weight, self.bias) and tuple(self.normalized_shape) == (x.shape[-1],):
+            return norm_train.layer_norm(x, self.weight, self.bias, self.eps)
+        return super().forward(x)
+
+
+class GroupNorm(nn.GroupNorm):
+    """nn.GroupNorm whose f32 training forward / backward run on the HIP kernels (norm_train.GroupNormActFn); torch otherwise"""
+
+    def forward(self, x):
+        from . import norm_train
+
+        if norm_train.group_norm_ok(x, self):
+            return norm_train.group_norm_act(x, self)
+        return super().forward(x)
+
+
 def group_norm(c, eps):
-    return nn.GroupNorm(32, c, eps=eps, affine=True)
+    return GroupNorm(32, c, eps=eps, affine=True)
 
 
 ACT_NONE, ACT_SILU, ACT_RELU = 0, 1, 2
@@ -439,9 +461,17 @@ def gn_act(norm: nn.GroupNorm, x, act=ACT_NONE, shift=None, residual=None):
         return ops.group_norm(x, norm.num_groups, w, b, norm.eps, act, shift, residual)
     if shift is not None:
         x = x + shift.to(x.dtype).reshape(-1, x.shape[1], 1, 1)
-    y = norm(x)
-    if residual is not None:
-        y = y + residual
+    from . import norm_train
+
+    if norm_train.group_norm_ok(x, norm):
+        # f32 training: HIP forward + backward, the activation (and its backward) inside the GroupNorm's passes
+        if residual is None:
+            return norm_train.group_norm_act(x, norm, act)
+        y = norm_train.group_norm_act(x, norm, ACT_NONE) + residual
+    else:
+        y = norm(x)
+        if residual is not None:
+            y = y + residual
     if act == ACT_SILU:
         return y * torch.sigmoid(y)
     return F.relu(y) if act == ACT_RELU else y
@@ -810,7 +840,7 @@ class BasicTransformerBlock(nn.Module):
         self.attn1 = CrossAttention(dim, None, heads, dim_head)
         self.ff = FeedForward(dim)
         self.attn2 = CrossAttention(dim, context_dim, heads, dim_head)
-        self.norm1, self.norm2, self.norm3 = nn.LayerNorm(dim), nn.LayerNorm(dim), nn.LayerNorm(dim)
+        self.norm1, self.norm2, self.norm3 = LayerNorm(dim), LayerNorm(dim), LayerNorm(dim)
 
     def forward(self, x, context):
         n1, n2, n3 = self.norm1, self.norm2, self.norm3
