@@ -393,6 +393,11 @@ int xm3d_add_layer_norm(const float* x, const void* delta, int32_t delta_dtype, 
 int64_t xm3d_layer_norm_bwd_ws_floats(int64_t rows, int32_t C);
 int xm3d_layer_norm_bwd(const float* x, const float* dy, const float* gamma, int64_t rows, int32_t C, float eps, float* dx, float* dgamma, float* dbeta,
                         float* ws, void* stream);
+/* out[j] = sum over rows of x[r, j]; x (rows, n) f32, row stride ld; ws: xm3d_column_sum_ws_floats(rows, n) floats.  The bias gradient of the
+ * trainable linear layers (run/train.py:504-540 through nn.Linear of msdeformattn.py:35-60 / mask2former_transformer_decoder.py): two launches,
+ * fixed summation order - bit-reproducible and safe inside a replayed HIP graph. */
+int64_t xm3d_column_sum_ws_floats(int64_t rows, int32_t n);
+int xm3d_column_sum(const float* x, int64_t rows, int32_t n, int64_t ld, float* out, float* ws, void* stream);
 /* Backward of xm3d_group_norm (NCHW f32, (B, C, hw) contiguous, hw % 4 == 0, B * C <= 65535) INCLUDING its fused activation (act 0 none / 1
  * SiLU / 2 ReLU): dx from x, dy, the forward's moments (`stats_ws` of xm3d_group_norm: sum and sum of squares per (sample, group), f64), gamma /
  * beta (f32 (C) or null).  dgamma / dbeta (C) or null (frozen norms).  ws: xm3d_group_norm_bwd_ws_floats(B, C, G) floats.  All sums in a

@@ -314,84 +314,36 @@ def test_training_iteration_matches_the_cpu_oracle(dev, monkeypatch):
         # measured 4e-6 .. 2.5e-4 for the heads, 2.3e-2 for the sparse stem's kernel (the gradient after ~55 sparse layers, f32 atomics in wgrad)
         assert rel < (5e-2 if "conv0p1s1" in n else 2e-3), (n, rel)
 
-    # the same iteration with the static stages replayed as HIP graphs (XMASK3d.enable_train_graphs: frozen UNet forward + backward,
-    # frozen VAE stages on the inference kernels, the trainable dense heads forward + backward) against the eager device iteration
+    # the same iteration, and two more on other views, with the static stages replayed as HIP graphs (XMASK3d.enable_train_graphs: frozen UNet
+    # forward + backward, frozen VAE stages on the inference kernels, the trainable dense heads forward + backward) against the eager device
+    # iteration: EVERY parameter gradient, on the capture pass and on replays with different data (a replayed graph must not depend on what
+    # the capture pass left in memory: torch's multi-block column sums do, tools/graph_reduce_probe.py - the linear layers' bias gradients
+    # come from xm3d_column_sum for that reason)
     graphed = copy.deepcopy(cpu).to(dev).train()
-    for p in graphed.parameters():
-        p.grad = None
     graphed.enable_train_graphs()
-    for rep in range(2):  # the second pass replays what the first captured
-        for p in graphed.parameters():
-            p.grad = None
-        monkeypatch.setattr(criterion, "_rand", seeded_rand())
-        losses_g, _ = graphed(batch)
-        sum(losses_g.values()).backward()
-        for k in sorted(losses_d):
-            a, b = float(losses_g[k]), float(losses_d[k])
-            assert abs(a - b) / max(abs(b), 1e-6) < 1e-4, (rep, k, a, b)
-        pg = dict(graphed.named_parameters())
-        for n in names:
-            rel = float((pg[n].grad - pd[n].grad).abs().max() / pd[n].grad.abs().max().clamp_min(1e-20))
-            print(f"[train graphs pass {rep}] grad {n:55s} rel to eager {rel:.2e}")
-            assert rel < (5e-2 if "conv0p1s1" in n else 2e-3), (rep, n, rel)
+    vox = pipeline.default_voxelizer(device=dev)
+    for rep, v in enumerate((view, 0, 3)):
+        b = batch if rep == 0 else pipeline.build_train_batch(sd, [v], vox, seed=11 + rep)
+        grads = []
+        for m in (gpu, graphed):
+            for p in m.parameters():
+                p.grad = None
+            monkeypatch.setattr(criterion, "_rand", seeded_rand())
+            losses_m, _ = m(b)
+            sum(losses_m.values()).backward()
+            grads.append(({k: float(x) for k, x in losses_m.items()}, {n: p.grad for n, p in m.named_parameters() if p.grad is not None}))
+        (le, ge), (lg, gg) = grads
+        for k in sorted(le):
+            assert abs(lg[k] - le[k]) / max(abs(le[k]), 1e-6) < 1e-4, (rep, k, lg[k], le[k])
+        assert set(ge) == set(gg)
+        worst = ("", 0.0)
+        for n in sorted(ge):
+            ref = float(ge[n].abs().max())
+            rel = float((gg[n] - ge[n]).abs().max()) / max(ref, 1e-12) if ref > 0 else float(gg[n].abs().max())
+            if rel > worst[1]:
+                worst = (n, rel)
+            # the sparse nets (eager in both runs) accumulate their weight gradients with f32 atomics: run-to-run noise of that size
+            tol = 5e-2 if (n.startswith("pc_") or "alpha" in n or "clip_project" in n or "time_embed" in n) else 2e-3
+            assert rel < tol, (rep, v, n, rel, ref)
+        print(f"[train graphs pass {rep} view {v}] {len(ge)} parameter gradients, worst relative difference to eager {worst[1]:.2e} ({worst[0]})")
     assert graphed._head_graphs and graphed.backbone.feature_extractor.ldm_extractor._vae_graphs
-
-
-@pytest.mark.parametrize("rows,C,affine", [(1000, 256, True), (4096 + 3, 320, True), (77, 1280, False), (5, 768, True), (20000, 256, True)])
-def test_layer_norm_training_kernels_match_torch_autograd(dev, rows, C, affine):
-    """norm_train.LayerNormFn (xm3d_layer_norm forward, xm3d_layer_norm_bwd backward) against F.layer_norm + autograd in f32;
-    the parameter gradients are bit-identical from run to run (fixed-order partial sums, no atomics)"""
-    import torch.nn.functional as F
-    from xmask3d_amd import norm_train
-
-    g = torch.Generator(device="cpu").manual_seed(rows + C)
-    x = (torch.randn(rows, C, generator=g) * 2 + 0.5).to(dev).requires_grad_(True)
-    w = torch.randn(C, generator=g).to(dev).requires_grad_(affine)
-    b = torch.randn(C, generator=g).to(dev).requires_grad_(affine)
-    dy = torch.randn(rows, C, generator=g).to(dev)
-    want = F.layer_norm(x, (C,), w, b, 1e-5)
-    gw = torch.autograd.grad(want, [x] + ([w, b] if affine else []), dy)
-    assert norm_train.layer_norm_ok(x, w, b)
-    got = norm_train.layer_norm(x, w, b, 1e-5)
-    gg = torch.autograd.grad(got, [x] + ([w, b] if affine else []), dy)
-    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
-    for a, r, tol in zip(gg, gw, (2e-5, 2e-4, 2e-4)):
-        assert (a - r).abs().max().item() <= tol * r.abs().max().item(), (rows, C, (a - r).abs().max().item(), r.abs().max().item())
-    if affine:
-        again = torch.autograd.grad(norm_train.layer_norm(x, w, b, 1e-5), [w, b], dy)
-        assert torch.equal(again[0], gg[1]) and torch.equal(again[1], gg[2])
-
-
-@pytest.mark.parametrize("B,C,H,W,act,affine", [(2, 256, 32, 32, 0, True), (1, 320, 64, 64, 1, False), (2, 512, 16, 24, 2, True), (1, 2560, 8, 8, 1, False),
-                                                (3, 64, 128, 128, 2, True)])
-def test_group_norm_training_kernels_match_torch_autograd(dev, B, C, H, W, act, affine):
-    """norm_train.GroupNormActFn (xm3d_group_norm forward with the activation fused, xm3d_group_norm_bwd backward through both) against
-    F.group_norm + SiLU / ReLU + autograd in f32"""
-    import torch.nn.functional as F
-    from xmask3d_amd import norm_train
-    from xmask3d_amd.sd_model import GroupNorm
-
-    g = torch.Generator(device="cpu").manual_seed(B * C + H)
-    x = (torch.randn(B, C, H, W, generator=g) * 1.5 + 0.3).to(dev).requires_grad_(True)
-    norm = GroupNorm(32, C, eps=1e-6).to(dev)
-    with torch.no_grad():
-        norm.weight.copy_(torch.randn(C, generator=g))
-        norm.bias.copy_(torch.randn(C, generator=g))
-    norm.requires_grad_(affine)
-    dy = torch.randn(B, C, H, W, generator=g).to(dev)
-
-    def ref():
-        y = F.group_norm(x, 32, norm.weight, norm.bias, 1e-6)
-        return y * torch.sigmoid(y) if act == 1 else (F.relu(y) if act == 2 else y)
-
-    wrt = [x] + ([norm.weight, norm.bias] if affine else [])
-    want = ref()
-    gw = torch.autograd.grad(want, wrt, dy)
-    assert norm_train.group_norm_ok(x, norm)
-    got = norm_train.group_norm_act(x, norm, act)
-    gg = torch.autograd.grad(got, wrt, dy)
-    assert (got - want).abs().max().item() <= 2e-5 * want.abs().max().item()
-    for a, r, tol in zip(gg, gw, (5e-5, 3e-4, 3e-4)):
-        assert (a - r).abs().max().item() <= tol * r.abs().max().item(), (C, act, (a - r).abs().max().item(), r.abs().max().item())
-    if act == 0:  # the module's plain call takes the same path
-        assert torch.equal(norm(x), got)

@@ -52,6 +52,8 @@ if world > 1: dist.barrier()
 t = time.perf_counter()
 for i in range(iters):
     l = it(i + 2)
+    if "trace" in sys.argv[3:] and rank == 0:
+        print(f"  iter {i + 2}: loss {l:.4f}", flush=True)
 torch.cuda.synchronize()
 if world > 1: dist.barrier()
 dt = (time.perf_counter() - t) / iters

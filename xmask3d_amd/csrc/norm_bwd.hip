@@ -295,3 +295,34 @@ extern "C" int xm3d_group_norm_bwd(const float* x, const float* dy, const double
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
+
+namespace xm3d {
+// per-workgroup partial column sums of a (rows, n) f32 matrix: workgroup w adds rows w, w + gridDim.x, ... (fixed order) for 256 columns
+__global__ __launch_bounds__(256) void k_colsum_part(const float* __restrict__ x, int64_t rows, int n, int64_t ld, float* __restrict__ part) {
+    const int j = blockIdx.y * 256 + threadIdx.x;
+    if (j >= n) return;
+    float t = 0.f;
+    for (int64_t r = blockIdx.x; r < rows; r += gridDim.x) t += x[r * ld + j];
+    part[int64_t(blockIdx.x) * n + j] = t;
+}
+}  // namespace xm3d
+
+static int colsum_parts(int64_t rows) { return int(rows < 256 ? (rows < 1 ? 1 : rows) : 256); }
+
+/* floats of workspace of xm3d_column_sum */
+extern "C" int64_t xm3d_column_sum_ws_floats(int64_t rows, int32_t n) { return int64_t(colsum_parts(rows)) * n; }
+
+/* out[j] = sum over rows of x[r, j], x (rows, n) f32 with row stride ld: the bias gradient of a linear layer.  Two launches, every sum in a
+ * fixed order: no atomics, no semaphores - bit-reproducible, and safe to replay from a HIP graph (torch's multi-block column reduction is not
+ * on this stack: tools/graph_reduce_probe.py). */
+extern "C" int xm3d_column_sum(const float* x, int64_t rows, int32_t n, int64_t ld, float* out, float* ws, void* stream) {
+    XM3D_REQUIRE(rows >= 0 && n > 0 && ld >= n, "column_sum: rows=%lld n=%d ld=%lld", (long long)rows, n, (long long)ld);
+    XM3D_REQUIRE(x && out && ws, "column_sum: null pointer");
+    hipStream_t s = as_stream(stream);
+    const int parts = colsum_parts(rows);
+    hipLaunchKernelGGL(k_colsum_part, dim3(parts, (n + 255) / 256), dim3(256), 0, s, x, rows, n, ld, ws);
+    XM3D_LAUNCH_CHECK();
+    hipLaunchKernelGGL(k_colsum, dim3((n + 255) / 256), dim3(256), 0, s, ws, parts, n, out, static_cast<float*>(nullptr), n);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}

@@ -78,3 +78,31 @@ def layer_norm(x, weight, bias, eps):
 
 def group_norm_act(x, norm, act=0):
     return GroupNormActFn.apply(x, norm.weight, norm.bias, norm.num_groups, norm.eps, act)
+
+
+class LinearFn(torch.autograd.Function):
+    """F.linear for f32 training with the bias gradient from xm3d_column_sum (fixed order; torch's multi-block column reduction does not
+    replay correctly from a HIP graph on this stack, tools/graph_reduce_probe.py); the two products stay on the library's GEMMs"""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        ctx.save_for_backward(x, weight)
+        ctx.has_bias = bias is not None
+        return torch.nn.functional.linear(x, weight, bias)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        d2 = dy.reshape(-1, dy.shape[-1])
+        if not d2.is_contiguous():
+            d2 = d2.contiguous()
+        gx = (d2 @ weight).view(x.shape) if ctx.needs_input_grad[0] else None
+        gw = d2.t() @ x.reshape(-1, x.shape[-1]) if ctx.needs_input_grad[1] else None
+        gb = ops.column_sum(d2) if (ctx.has_bias and ctx.needs_input_grad[2]) else None
+        return gx, gw, gb
+
+
+def linear_ok(x, weight):
+    return (not _OFF and x.is_cuda and torch.is_grad_enabled() and x.dtype == torch.float32 and weight.dtype == torch.float32
+            and not torch.is_autocast_enabled("cuda") and weight.requires_grad and x.numel() > 0)

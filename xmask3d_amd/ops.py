@@ -508,6 +508,17 @@ def layer_norm_bwd(x, dy, weight, eps, need_affine):
     return dx, dg, db
 
 
+def column_sum(x):
+    """(rows, n) contiguous f32 device tensor -> (n,) column sums in a fixed order (xm3d_column_sum)"""
+    if not (x.is_cuda and x.dtype == torch.float32 and x.dim() == 2 and x.is_contiguous()):
+        raise TypeError("column_sum: contiguous 2-D f32 device tensor required")
+    rows, n = x.shape
+    out = torch.empty(n, dtype=torch.float32, device=x.device)
+    ws = torch.empty(lib().xm3d_column_sum_ws_floats(rows, n), dtype=torch.float32, device=x.device)
+    check(lib().xm3d_column_sum(_ptr(x), rows, n, n, _ptr(out), _ptr(ws), _stream()), "xm3d_column_sum")
+    return out
+
+
 def bias_residual(a, b, bias, stats_groups=None):
     """out = a + b + bias[c] for channels-last (B,C,H,W) f32/bf16 device tensors; a may be None.
     stats_groups: G of the GroupNorm expected to read the result (its statistics are then computed here, on the way)."""
