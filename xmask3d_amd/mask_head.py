@@ -309,6 +309,29 @@ class MSDeformAttnPixelDecoder(nn.Module):
 
 
 # ----------------------------------------------------------------------------- transformer decoder
+def _mha_train_ok(mha, x):
+    return (x.is_cuda and torch.is_grad_enabled() and x.dtype == torch.float32 and mha.in_proj_weight is not None and mha.in_proj_weight.dtype == torch.float32
+            and not torch.is_autocast_enabled("cuda") and mha.dropout == 0.0 and not mha.batch_first)
+
+
+def _mha_train(mha, query, key, value, attn_mask=None):
+    """nn.MultiheadAttention(query, key, value, attn_mask)[0] for f32 training on a device, (L, B, E) layout, with the three input projections
+    and the output projection through flinear (their bias gradients then come from xm3d_column_sum: torch's own column reduction does not
+    replay from a HIP graph on this stack) and the attention itself through scaled_dot_product_attention (exact f32 math backend).
+    attn_mask: (B * heads, Lq, Lk) bool, True = may NOT attend (the module's convention)."""
+    E, H = mha.embed_dim, mha.num_heads
+    w, b = mha.in_proj_weight, mha.in_proj_bias
+    q = flinear(query, w[:E], None if b is None else b[:E])
+    k = flinear(key, w[E:2 * E], None if b is None else b[E:2 * E])
+    v = flinear(value, w[2 * E:], None if b is None else b[2 * E:])
+    Lq, B = q.shape[:2]
+    Lk = k.shape[0]
+    q, k, v = (t.reshape(t.shape[0], B, H, E // H).permute(1, 2, 0, 3) for t in (q, k, v))
+    allowed = None if attn_mask is None else ~attn_mask.view(B, H, Lq, Lk)
+    o = F.scaled_dot_product_attention(q, k, v, attn_mask=allowed)
+    return flinear(o.permute(2, 0, 1, 3).reshape(Lq, B, E), mha.out_proj.weight, mha.out_proj.bias)
+
+
 class SelfAttentionLayer(nn.Module):
     def __init__(self, d_model, nhead, dropout=0.0):
         super().__init__()
@@ -340,6 +363,8 @@ class SelfAttentionLayer(nn.Module):
                 o = torch.empty((L, B, E), dtype=torch.float32, device=tgt.device)
                 ops.attention_f32(q4, k4, v4, out=o.view(L, B, H, E // H).transpose(0, 1))
                 return self.norm(tgt + flinear(o, mha.out_proj.weight, mha.out_proj.bias))
+        if _mha_train_ok(mha, tgt):
+            return self.norm(tgt + _mha_train(mha, q, k, tgt))
         return self.norm(tgt + self.self_attn(q, k, value=tgt, need_weights=False)[0])
 
     def forward_stream(self, st, query_pos):
@@ -378,6 +403,8 @@ class CrossAttentionLayer(nn.Module):
         with the bias broadcast over the heads instead of replicated and converted per call."""
         key = memory + pos if key is None else key
         if memory_bias is None:
+            if _mha_train_ok(self.multihead_attn, tgt) and (memory_mask is None or memory_mask.dtype == torch.bool):
+                return self.norm(tgt + _mha_train(self.multihead_attn, tgt + query_pos, key, memory, memory_mask))
             tgt2 = self.multihead_attn(query=tgt + query_pos, key=key, value=memory, attn_mask=memory_mask, need_weights=False)[0]
             return self.norm(tgt + tgt2)
         mha = self.multihead_attn
