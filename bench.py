@@ -349,7 +349,8 @@ def train_leg(args, cfg, dev, rank, world, backend, sd, voxelizer, log, train_dt
     return {"iters_per_s": args.train_steps / dt, "ms_per_iter": dt / args.train_steps * 1e3, "steps": args.train_steps,
             "views_per_gpu": 1, "global_batch_views": world, "frozen_nets_dtype": train_dtype,
             "scope": "forward + 37 weighted losses (Hungarian matching of all 10 decoder outputs in one HIP launch) + backward + AdamW; frozen UNet "
-                     "forward/backward replayed as HIP graphs; DDP gradient all-reduce + MinkowskiSyncBatchNorm when n_gpus > 1"}
+                     "forward/backward and the frozen VAE stages (inference kernels) replayed as HIP graphs; LayerNorm / GroupNorm forward + backward and "
+                     "the linear layers' bias gradients on own fixed-order kernels; DDP gradient all-reduce + MinkowskiSyncBatchNorm when n_gpus > 1"}
 
 
 def main():

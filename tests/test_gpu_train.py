@@ -315,10 +315,9 @@ def test_training_iteration_matches_the_cpu_oracle(dev, monkeypatch):
         assert rel < (5e-2 if "conv0p1s1" in n else 2e-3), (n, rel)
 
     # the same iteration, and two more on other views, with the static stages replayed as HIP graphs (XMASK3d.enable_train_graphs: frozen UNet
-    # forward + backward, frozen VAE stages on the inference kernels, the trainable dense heads forward + backward) against the eager device
-    # iteration: EVERY parameter gradient, on the capture pass and on replays with different data (a replayed graph must not depend on what
-    # the capture pass left in memory: torch's multi-block column sums do, tools/graph_reduce_probe.py - the linear layers' bias gradients
-    # come from xm3d_column_sum for that reason)
+    # forward + backward, frozen VAE stages on the inference kernels) against the eager device iteration: EVERY parameter gradient, on the
+    # capture pass and on replays with different data (a replayed graph must not depend on what the capture pass left in memory: torch's
+    # multi-block reductions do on this stack, tools/graph_reduce_probe.py - which is why the trainable heads are NOT graphed by default)
     graphed = copy.deepcopy(cpu).to(dev).train()
     graphed.enable_train_graphs()
     vox = pipeline.default_voxelizer(device=dev)
@@ -350,4 +349,4 @@ def test_training_iteration_matches_the_cpu_oracle(dev, monkeypatch):
                 bad.append((n, rel, ref))
         assert not bad, (rep, v, len(bad), sorted(bad, key=lambda t: -t[1])[:12])
         print(f"[train graphs pass {rep} view {v}] {len(ge)} parameter gradients, worst relative difference to eager {worst[1]:.2e} ({worst[0]})")
-    assert graphed._head_graphs and graphed.backbone.feature_extractor.ldm_extractor._vae_graphs
+    assert graphed._head_graphs is None and graphed.backbone.feature_extractor.ldm_extractor._vae_graphs

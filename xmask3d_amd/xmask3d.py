@@ -242,16 +242,22 @@ class XMASK3d(nn.Module):
 
     _head_graphs = None
 
-    def enable_train_graphs(self, on=True):
-        """Training at one static view shape per GPU: the frozen UNet's forward + backward (image_branch._GraphedTaps), the frozen VAE
-        stages (gradient-free, inference kernels) and the TRAINABLE dense heads - feature projections, pixel decoder, transformer
-        decoder: forward and backward - replay as HIP graphs (train_graph.GraphedRegion; the parameters' gradients arrive through
-        their ordinary AccumulateGrad nodes, so DDP and the optimizer are unchanged).  The sparse 3D nets, the Hungarian matching
-        and the losses have data-dependent shapes and stay eager."""
+    def enable_train_graphs(self, on=True, heads=False):
+        """Training at one static view shape per GPU: the frozen UNet's forward + backward (image_branch._GraphedTaps) and the frozen VAE
+        stages (gradient-free, on the inference kernels) replay as HIP graphs.  The sparse 3D nets, the Hungarian matching and the losses
+        have data-dependent shapes and stay eager.
+
+        heads=True (OPT-IN, not validated): also the TRAINABLE dense heads - feature projections, pixel decoder, transformer decoder,
+        forward and backward - as one graph pair (train_graph.GraphedRegion; parameter gradients arrive through their ordinary
+        AccumulateGrad nodes).  Measured in round 4: with the frozen stages graphed the iteration is device-bound (157 ms of kernels in
+        a 158 ms iteration), so this buys nothing - and torch's multi-block reductions (bias gradients of convolutions, gradients of
+        broadcast parameters) return stale values when replayed from a HIP graph on this stack (tools/graph_reduce_probe.py;
+        tests/test_gpu_train.py found mask_features.bias and level_embed wrong).  The linear layers, LayerNorm and GroupNorm are safe
+        (own fixed-order reductions: xm3d_column_sum, xm3d_layer_norm_bwd, xm3d_group_norm_bwd); the remaining aten reductions are not."""
         ext = self.backbone.feature_extractor.ldm_extractor
         ext.enable_train_graph(on)
         ext.enable_vae_train_path(on)
-        self._head_graphs = {} if on else None
+        self._head_graphs = {} if (on and heads) else None
         return self
 
     def _decode_heads_graphed(self, img, cond):
