@@ -108,12 +108,17 @@ class _GraphedTapsFn(torch.autograd.Function):
             g.emb.copy_(emb)
         g.fwd.replay()
         c.g = g
+        g.generation = getattr(g, "generation", 0) + 1
+        c.generation = g.generation  # the backward graph reads the activations THIS replay left in the pool
         return tuple(o.detach().clone() for o in g.outs)  # the static outputs are overwritten by the next replay
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(c, *grads):
         g = c.g
+        if c.generation != g.generation:
+            raise RuntimeError("graphed UNet: backward of a forward whose activations a later forward of the same shape has overwritten "
+                               "(two forwards before their backwards: gradient accumulation over views needs enable_train_graph(False))")
         for dst, src in zip(g.gouts, grads):
             if src is None:
                 dst.zero_()
@@ -377,12 +382,14 @@ class GNBottleneck(nn.Module):
             gamma, beta = _gn_f32(self.conv1.norm)
             n1 = self.conv1.norm
             gn = (ops.gn_stats_of(c1, n1.num_groups), gamma, beta, n1.eps, n1.num_groups, "relu")
+            n2 = self.conv2.norm  # the epilogue's moments need whole 4-channel groups per lane (xm3d_conv3x3_nhwc); else conv2's GroupNorm takes its own pass
+            sg = n2.num_groups if (self.conv2.out_channels // n2.num_groups) % 4 == 0 else None
             if c1.dtype == torch.float32:  # fp32 configuration: the f32-accurate form on split bf16 operands
                 packs, tile, _ = _packed_split(self.conv2)
-                c2 = ops.conv3x3_f32(c1, packs, self.conv2.out_channels, tile, gn=gn, stats_groups=self.conv2.norm.num_groups)
+                c2 = ops.conv3x3_f32(c1, packs, self.conv2.out_channels, tile, gn=gn, stats_groups=sg)
             else:
                 packed, tile, _ = _packed(self.conv2)
-                c2 = ops.conv3x3(c1, packed, self.conv2.out_channels, tile, gn=gn, stats_groups=self.conv2.norm.num_groups)
+                c2 = ops.conv3x3(c1, packed, self.conv2.out_channels, tile, gn=gn, stats_groups=sg)
             return self.conv3(gn_act(self.conv2.norm, c2, ACT_RELU), residual=res, relu=True)
         return self.conv3(self.conv2(gn_act(self.conv1.norm, c1, ACT_RELU)), residual=res, relu=True)
 

@@ -693,7 +693,7 @@ def gemm_supported(x, n_rows, k=None):
     """x: (..., K) bf16 on the GPU whose rows are contiguous and evenly strided; K % 64, N % 32"""
     k = x.shape[-1] if k is None else k
     return (x.is_cuda and x.dtype == torch.bfloat16 and x.dim() >= 2 and x.shape[-1] == k and k % 64 == 0 and n_rows % 32 == 0
-            and x.numel() > 0 and _rows_of(x) is not None)
+            and x.numel() > 0 and _rows_of(x) is not None and x.data_ptr() % 16 == 0)
 
 
 def _rows_of(x):

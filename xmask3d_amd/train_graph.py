@@ -97,6 +97,8 @@ class _GraphedRegionFn(torch.autograd.Function):
                 dst.copy_(src)
         g.fwd.replay()
         c.g, c.n_in = g, n_in
+        g.generation = getattr(g, "generation", 0) + 1
+        c.generation = g.generation
         outs = tuple(o.detach().clone() for o in g.outs)
         c.mark_non_differentiable(*[o for j, o in enumerate(outs) if j not in set(g.diff)])
         return outs
@@ -105,6 +107,8 @@ class _GraphedRegionFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(c, *grads):
         g = c.g
+        if c.generation != g.generation:
+            raise RuntimeError("graphed region: backward of a forward whose activations a later forward of the same shapes has overwritten")
         for dst, j in zip(g.gouts, g.diff):
             if grads[j] is None:
                 dst.zero_()
