@@ -417,6 +417,11 @@ int xm3d_quick_gelu(const void* x, int32_t dtype, int64_t numel, void* out, void
  * AttnBlock; models/modeling/meta_arch/ldm.py:448-482) - see pointwise.hip. */
 int xm3d_softmax_rows_f32_bf16(const float* scores, int64_t rows, int32_t cols, float scale, void* probs, void* stream);
 
+/* blocked (maps, (S/P)^2) u8 = max_pool2d(sigmoid(bilinear_resize(logits (maps, h, w) f32 -> (S, S), align_corners = False)), P, stride P) < 0.5: the
+ * patch mask of mask-CLIP (models/modeling/meta_arch/clip.py:272-310: F.interpolate + sigmoid + F.max_pool2d + compare) without the (maps, S, S)
+ * intermediate.  S % P == 0. */
+int xm3d_clip_mask_blocked(const float* logits, int64_t maps, int32_t h, int32_t w, int32_t S, int32_t P, uint8_t* blocked, void* stream);
+
 /* ---- masked cross-attention bias (replaces the mask handling of Mask2Former's decoder, XMask3D copy
  * third_party/.../odise.py:395,445-491: bilinear shrink -> sigmoid -> < 0.5 -> repeat over heads -> all/and-not -> -inf fill).
  * logits (maps, H, W) mask logits (maps = B*Q), in_dtype/out_dtype 0 = f32, 1 = bf16; (H,W) -> (h,w) must be a shrink by

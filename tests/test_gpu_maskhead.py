@@ -81,3 +81,22 @@ def test_decoder_heads_use_the_fused_path_and_match_the_op_chain(monkeypatch):
     assert own.dtype == torch.float32
     # the chain's own error (bf16 mask / count, bf16 product) on these zero-mean features is ~5 % of the largest mean: measured 0.009 of 0.205
     assert float((own - chain.float()).abs().max()) <= 5e-2 * float(chain.float().abs().max()) + 5e-3
+
+
+@pytest.mark.parametrize("B,Q,h,w", [(2, 50, 128, 128), (1, 7, 64, 96), (3, 5, 32, 32)])
+def test_clip_mask_blocked_matches_the_torch_chain(B, Q, h, w):
+    """xm3d_clip_mask_blocked == (max_pool2d(sigmoid(interpolate(logits, 224, bilinear)), 14, 14) < 0.5) of mask-CLIP (meta_arch/clip.py:272-310).
+    The kernel evaluates torch's bilinear arithmetic term for term; a product fused differently by the compiler can move a value that sits within
+    one ulp of the threshold, so the comparison allows 1e-4 of the patches to differ (measured: 0)."""
+    import torch.nn.functional as F
+    from xmask3d_amd import ops
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator(device="cpu").manual_seed(B * Q + h)
+    base = torch.randn(B, Q, h // 8, w // 8, generator=g)
+    logits = (F.interpolate(base, size=(h, w), mode="bicubic") * 3 + torch.randn(B, Q, h, w, generator=g) * 0.3).to(dev).contiguous()
+    want = (F.max_pool2d(F.interpolate(logits, size=(224, 224), mode="bilinear", align_corners=False).sigmoid(), 14, 14) < 0.5).reshape(B, Q, -1)
+    got = ops.clip_mask_blocked(logits, 224, 14)
+    assert got.shape == want.shape and got.dtype == torch.bool
+    assert (got != want).float().mean().item() <= 1e-4
+    assert 0.05 < want.float().mean().item() < 0.95  # both classes present: the test means something

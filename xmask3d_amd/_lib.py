@@ -113,6 +113,7 @@ _SIGS = {
     "xm3d_group_norm_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_vp, c_vp, c_i64, c_i32, c_i32, c_i32, ctypes.c_float, c_i32, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_column_sum_ws_floats": (ctypes.c_int64, [c_i64, c_i32]),
     "xm3d_column_sum": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_vp]),
+    "xm3d_clip_mask_blocked": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_pad_nhwc": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp, c_vp]),
     "xm3d_quick_gelu": (ctypes.c_int, [c_vp, c_i32, c_i64, c_vp, c_vp]),
     "xm3d_softmax_rows_f32_bf16": (ctypes.c_int, [c_vp, c_i64, c_i32, ctypes.c_float, c_vp, c_vp]),

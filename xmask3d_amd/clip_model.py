@@ -18,6 +18,8 @@ import zlib
 from collections import OrderedDict
 
 import numpy as np
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -252,13 +254,14 @@ class MaskCLIP(ClipAdapter):
     def logit_scale(self):
         return torch.clamp(self.clip.logit_scale.exp(), max=100)
 
-    def encode_image_with_mask(self, image, mask):
+    def encode_image_with_mask(self, image, mask, blocked=None):
+        """blocked (b, q, patches) bool: the patch mask when the caller has it already (ops.clip_mask_blocked); `mask` is then only read for its shape"""
         v = self.clip.visual
         image = self.clip_preprocess(image.float())
-        mask = mask.float()
         b, q = mask.shape[:2]
         patch = v.conv1.kernel_size
-        blocked = (F.max_pool2d(mask.sigmoid(), kernel_size=patch, stride=v.conv1.stride) < 0.5).reshape(b, q, -1)
+        if blocked is None:
+            blocked = (F.max_pool2d(mask.float().sigmoid(), kernel_size=patch, stride=v.conv1.stride) < 0.5).reshape(b, q, -1)
         n_img = v.positional_embedding.shape[0] - 1
         total = q + 1 + n_img
         # allow[b, row, col]: nobody attends to mask tokens; a mask token sees the class token and its own patches
@@ -275,6 +278,14 @@ class MaskCLIP(ClipAdapter):
 
     def get_mask_embed(self, image, mask):
         image = F.interpolate(image, size=self.image_size, mode="bilinear", align_corners=False)
+        v = self.clip.visual
+        S, P = image.shape[-1], v.conv1.kernel_size[0]
+        if mask.is_cuda and not torch.is_grad_enabled() and mask.dtype == torch.float32 and mask.is_contiguous() and image.shape[-2] == S \
+                and tuple(v.conv1.kernel_size) == tuple(v.conv1.stride) == (P, P) and S % P == 0 and os.environ.get("XM3D_CLIP_MASK", "hip") != "library":
+            # inference: the patch mask straight from the mask logits (resize + sigmoid + max-pool + compare in one pass, no (B, Q, S, S) tensor)
+            from . import ops
+
+            return self.encode_image_with_mask(image, mask, blocked=ops.clip_mask_blocked(mask, S, P))
         mask = F.interpolate(mask, size=image.shape[-2:], mode="bilinear", align_corners=False)
         return self.encode_image_with_mask(image, mask)
 

@@ -94,3 +94,50 @@ extern "C" int xm3d_attn_mask_bias(const void* logits, int32_t in_dtype, int64_t
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
+
+// ---- mask-CLIP's patch mask (XMask3D copy of ODISE's MaskCLIP.encode_image_with_mask, /root/reference/models/modeling/meta_arch/clip.py:272-310):
+//     blocked[b, q, patch] = max_pool2d(sigmoid(interpolate(mask_logits, (S, S), bilinear)), P, stride P) < 0.5
+// without the (B, Q, S, S) f32 intermediate (S = 224: 200 MB per 20-view forward written and read twice).  One thread per (map, patch): the
+// bilinear samples of its P x P output pixels (torch's align_corners = False arithmetic, term for term), their maximum (sigmoid is monotone: the
+// maximum of the sigmoids is the sigmoid of the maximum), ONE sigmoid and the comparison.
+namespace xm3d {
+__global__ __launch_bounds__(256) void k_clip_mask_blocked(const float* __restrict__ logits, int64_t maps, int h, int w, int S, int P, int np,
+                                                           uint8_t* __restrict__ blocked) {
+    const int64_t i = int64_t(blockIdx.x) * 256 + threadIdx.x;
+    if (i >= maps * np * np) return;
+    const int px = int(i % np), py = int((i / np) % np);
+    const int64_t m = i / (int64_t(np) * np);
+    const float* p = logits + m * int64_t(h) * w;
+    const float rh = float(h) / float(S), rw = float(w) / float(S);
+    float best = -INFINITY;
+    for (int oy = py * P; oy < py * P + P; ++oy) {
+        float sy = rh * (float(oy) + 0.5f) - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        const int y0 = int(sy), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const float ly = sy - float(y0), hy = 1.f - ly;
+        for (int ox = px * P; ox < px * P + P; ++ox) {
+            float sx = rw * (float(ox) + 0.5f) - 0.5f;
+            sx = sx < 0.f ? 0.f : sx;
+            const int x0 = int(sx), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const float lx = sx - float(x0), hx = 1.f - lx;
+            const float v = hy * (hx * p[y0 * w + x0] + lx * p[y0 * w + x1]) + ly * (hx * p[y1 * w + x0] + lx * p[y1 * w + x1]);
+            best = fmaxf(best, v);
+        }
+    }
+    const float sg = 1.f / (1.f + expf(-best));
+    blocked[i] = sg < 0.5f ? 1 : 0;
+}
+}  // namespace xm3d
+
+extern "C" int xm3d_clip_mask_blocked(const float* logits, int64_t maps, int32_t h, int32_t w, int32_t S, int32_t P, uint8_t* blocked, void* stream) {
+    XM3D_REQUIRE(maps >= 0 && h > 0 && w > 0 && S > 0 && P > 0 && S % P == 0, "clip_mask_blocked: maps=%lld h=%d w=%d S=%d P=%d (S %% P == 0)", (long long)maps, h, w,
+                 S, P);
+    if (maps == 0) return XM3D_OK;
+    XM3D_REQUIRE(logits && blocked, "clip_mask_blocked: null pointer");
+    const int np = S / P;
+    const int64_t total = maps * np * np;
+    XM3D_REQUIRE((total + 255) / 256 < (int64_t(1) << 31), "clip_mask_blocked: grid too large");
+    hipLaunchKernelGGL(xm3d::k_clip_mask_blocked, dim3(unsigned((total + 255) / 256)), dim3(256), 0, xm3d::as_stream(stream), logits, maps, h, w, S, P, np, blocked);
+    XM3D_LAUNCH_CHECK();
+    return XM3D_OK;
+}

@@ -1169,6 +1169,18 @@ def add_layer_norm(x, delta, weight, bias, eps=1e-5, pos=None, want=("f32", "bf1
     return res[0] if len(res) == 1 else res
 
 
+def clip_mask_blocked(logits, size, patch):
+    """(B, Q, h, w) f32 contiguous mask logits -> (B, Q, (size/patch)^2) bool: max-pooled sigmoid of the bilinear resize to (size, size) < 0.5
+    (xm3d_clip_mask_blocked: mask-CLIP's patch mask without the resized intermediate)"""
+    if not (logits.is_cuda and logits.dtype == torch.float32 and logits.dim() == 4 and logits.is_contiguous() and size % patch == 0):
+        raise TypeError("clip_mask_blocked: contiguous (B, Q, h, w) f32 device tensor and size % patch == 0 required")
+    B, Q, h, w = logits.shape
+    n = (size // patch) ** 2
+    out = torch.empty((B, Q, n), dtype=torch.uint8, device=logits.device)
+    check(lib().xm3d_clip_mask_blocked(_ptr(logits), B * Q, h, w, int(size), int(patch), _ptr(out), _stream()), "xm3d_clip_mask_blocked")
+    return out.view(torch.bool)
+
+
 def pad_bottom_right_nhwc(x, pad_bottom, pad_right):
     """channels-last (B,C,H,W) f32/bf16 device tensor -> (B,C,H+pad_bottom,W+pad_right) channels-last, zero padded, one pass"""
     if x.dtype not in (torch.float32, torch.bfloat16) or not is_nhwc(x):

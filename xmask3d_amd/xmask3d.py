@@ -487,8 +487,10 @@ class XMASK3d(nn.Module):
         hd = getattr(self, "heads_cast", None)
         if hd is not None:
             if getattr(self, "_fuser_w3d", None) is None or self._fuser_w3d.device != dev:
-                self._fuser_w3d = lin.weight[:, C:].to(hd).t().contiguous()
-            part3d = (p3d.to(hd) @ self._fuser_w3d).float()
+                self._fuser_w3d = lin.weight[:, C:].to(hd).contiguous()      # (out, in): the point-wise half of the merger's weight
+            from .sd_model import flinear
+
+            part3d = flinear(p3d.to(hd), self._fuser_w3d).float()            # k_gemm (bf16, f32 accumulation)
         else:
             part3d = p3d @ lin.weight[:, C:].t()
         part2d = (emb @ lin.weight[:, :C].t().float() + lin.bias.float())[vid, own_p.clamp_min(0)]   # (B, Q, 768) -> per point
