@@ -380,11 +380,11 @@ int xm3d_layer_norm(const void* x, const void* delta, int32_t dtype, int64_t row
                     void* sum_out, void* y, void* stream);
 /* y = LayerNorm(x + delta) * gamma + beta over an f32 residual stream x (rows, C), C % 4 == 0, C <= 1024; delta f32 (delta_dtype 0) /
  * bf16 (1) / null.  Written as any of: y (f32), y_bf = bf16(y), ypos_bf = bf16(y + pos) with pos (pos_rows, C) f32 (pos_dtype 0) / bf16 (1),
- * stream row r reading pos row r % pos_rows.  The post-norm residual blocks of the pixel decoder's deformable-attention encoder and of the
+ * stream row r reading pos row r % pos_rows; out_dtype 0 writes y_bf / ypos_bf as f32 instead (the fp32 configuration: ypos = y + pos).  The post-norm residual blocks of the pixel decoder's deformable-attention encoder and of the
  * masked-attention transformer decoder under bf16 inference (/root/reference/models/modeling/pixel_decoder/msdeformattn.py:35-60,
  * .../transformer_decoder/mask2former_transformer_decoder.py:17-178): one launch instead of cast + add + LayerNorm + add + casts. */
 int xm3d_add_layer_norm(const float* x, const void* delta, int32_t delta_dtype, int64_t rows, int32_t C, const float* gamma, const float* beta,
-                        float eps, const void* pos, int32_t pos_dtype, int64_t pos_rows, float* y, void* y_bf, void* ypos_bf, void* stream);
+                        float eps, const void* pos, int32_t pos_dtype, int64_t pos_rows, float* y, void* y_bf, void* ypos_bf, int32_t out_dtype, void* stream);
 /* Backward of LayerNorm over (rows, C) f32, C % 4 == 0, C <= 2048 (<= 1024 with parameter gradients): dx from x, dy, gamma (f32 or null) - the
  * row statistics are recomputed, nothing but x is kept from the forward.  dgamma / dbeta (C) or null; with either, ws =
  * xm3d_layer_norm_bwd_ws_floats(rows, C) floats of scratch (per-workgroup partial rows, added in index order: no atomics, bit-reproducible).

@@ -353,3 +353,7 @@ def test_add_layer_norm_matches_the_torch_chain(dev, rows, C, prow, ddt, pdt):
     assert torch.equal(yp, (y.view(rows // prow, prow, C) + pos.float()).view(rows, C).to(torch.bfloat16))
     only = ops.add_layer_norm(x, d, w, b, 1e-5, want=("bf16",))
     assert torch.equal(only, yb)
+    # the fp32 configuration's form: y and y + pos in f32
+    y32, yp32 = ops.add_layer_norm(x, d, w, b, 1e-5, pos=pos, want=("f32", "pos"), out_dtype=torch.float32)
+    assert torch.equal(y32, y) and yp32.dtype == torch.float32
+    assert torch.equal(yp32, (y.view(rows // prow, prow, C) + pos.float()).view(rows, C))

@@ -106,7 +106,7 @@ _SIGS = {
     "xm3d_compute_mapping": (ctypes.c_int, [c_vp, c_i64, c_vp, c_vp, c_i32, c_i32, c_i32, c_vp, c_i32, c_i32, ctypes.c_double, c_vp, c_vp]),
     "xm3d_geglu": (ctypes.c_int, [c_vp, c_i32, c_i64, c_i32, c_vp, c_vp]),
     "xm3d_layer_norm": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, ctypes.c_float, c_vp, c_vp, c_vp]),
-    "xm3d_add_layer_norm": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, ctypes.c_float, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_vp]),
+    "xm3d_add_layer_norm": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i64, c_i32, c_vp, c_vp, ctypes.c_float, c_vp, c_i32, c_i64, c_vp, c_vp, c_vp, c_i32, c_vp]),
     "xm3d_layer_norm_bwd_ws_floats": (ctypes.c_int64, [c_i64, c_i32]),
     "xm3d_layer_norm_bwd": (ctypes.c_int, [c_vp, c_vp, c_vp, c_i64, c_i32, ctypes.c_float, c_vp, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_group_norm_bwd_ws_floats": (ctypes.c_int64, [c_i64, c_i32, c_i32]),

@@ -92,11 +92,24 @@ __global__ __launch_bounds__(256) void k_layer_norm(const T* __restrict__ x, con
 // query / key input "with positional embedding"; pos f32 or bf16, row r of the stream reads pos row r % pos_rows: a batch-broadcast
 // embedding).  One launch instead of cast + add + LayerNorm + add + two casts; the arithmetic per element is the chain's (f32 add, f32
 // LayerNorm, f32 add, one rounding to bf16).  One wave per row, C <= 1024, 16-byte accesses.
-template <typename TD, typename TP>
+template <typename TO>
+__device__ __forceinline__ void aln_store(TO* dst, const float (&o)[4]) {
+    if constexpr (sizeof(TO) == 4) {
+        *reinterpret_cast<float4*>(dst) = make_float4(o[0], o[1], o[2], o[3]);
+    } else {
+        __hip_bfloat16 q[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) q[j] = __float2bfloat16(o[j]);
+        *reinterpret_cast<uint2*>(dst) = *reinterpret_cast<const uint2*>(q);
+    }
+}
+
+// TO: type of the second and third output (bf16: the bf16 configuration's GEMM inputs; float: the fp32 configuration, where only `stream + pos`
+// is a new tensor and y_bf is not asked for)
+template <typename TD, typename TP, typename TO>
 __global__ __launch_bounds__(256) void k_add_layer_norm(const float* __restrict__ x, const TD* __restrict__ delta, const float* __restrict__ gamma,
                                                         const float* __restrict__ beta, int64_t rows, int C, float eps, const TP* __restrict__ pos,
-                                                        int64_t pos_rows, float* __restrict__ y, __hip_bfloat16* __restrict__ y_bf,
-                                                        __hip_bfloat16* __restrict__ ypos_bf) {
+                                                        int64_t pos_rows, float* __restrict__ y, TO* __restrict__ y_bf, TO* __restrict__ ypos_bf) {
     constexpr int VPL = 4;  // float4 vectors per lane: C <= 64 * 4 * 4
     const int lane = threadIdx.x & 63;
     const int64_t row = int64_t(blockIdx.x) * 4 + (threadIdx.x >> 6);
@@ -151,12 +164,7 @@ __global__ __launch_bounds__(256) void k_add_layer_norm(const float* __restrict_
             float o[4] = {fmaf((v[i][0] - mean) * rstd, g.x, b.x), fmaf((v[i][1] - mean) * rstd, g.y, b.y), fmaf((v[i][2] - mean) * rstd, g.z, b.z),
                           fmaf((v[i][3] - mean) * rstd, g.w, b.w)};
             if (y) *reinterpret_cast<float4*>(y + row * C + e * 4) = make_float4(o[0], o[1], o[2], o[3]);
-            if (y_bf) {
-                __hip_bfloat16 q[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) q[j] = __float2bfloat16(o[j]);
-                *reinterpret_cast<uint2*>(y_bf + row * C + e * 4) = *reinterpret_cast<const uint2*>(q);
-            }
+            if (y_bf) aln_store<TO>(y_bf + row * C + e * 4, o);
             if (ypos_bf) {
                 float p[4];
                 if constexpr (sizeof(TP) == 4) {
@@ -167,10 +175,8 @@ __global__ __launch_bounds__(256) void k_add_layer_norm(const float* __restrict_
                     p[0] = __uint_as_float(t.x << 16), p[1] = __uint_as_float(t.x & 0xFFFF0000u);
                     p[2] = __uint_as_float(t.y << 16), p[3] = __uint_as_float(t.y & 0xFFFF0000u);
                 }
-                __hip_bfloat16 q[4];
-#pragma unroll
-                for (int j = 0; j < 4; ++j) q[j] = __float2bfloat16(o[j] + p[j]);
-                *reinterpret_cast<uint2*>(ypos_bf + row * C + e * 4) = *reinterpret_cast<const uint2*>(q);
+                const float op[4] = {o[0] + p[0], o[1] + p[1], o[2] + p[2], o[3] + p[3]};
+                aln_store<TO>(ypos_bf + row * C + e * 4, op);
             }
         }
     }
@@ -207,13 +213,17 @@ extern "C" int xm3d_layer_norm(const void* x, const void* delta, int32_t dtype, 
     return XM3D_OK;
 }
 
-// delta_dtype / pos_dtype: 0 = f32, 1 = bf16 (ignored when the pointer is null).  Any of y / y_bf / ypos_bf may be null (not all); ypos_bf needs pos.
+// delta_dtype / pos_dtype / out_dtype: 0 = f32, 1 = bf16 (ignored when the pointer is null); out_dtype is the type of y_bf and ypos_bf.  Any of
+// y / y_bf / ypos_bf may be null (not all); ypos_bf needs pos.
 extern "C" int xm3d_add_layer_norm(const float* x, const void* delta, int32_t delta_dtype, int64_t rows, int32_t C, const float* gamma, const float* beta,
-                                   float eps, const void* pos, int32_t pos_dtype, int64_t pos_rows, float* y, void* y_bf, void* ypos_bf, void* stream) {
+                                   float eps, const void* pos, int32_t pos_dtype, int64_t pos_rows, float* y, void* y_bf, void* ypos_bf, int32_t out_dtype,
+                                   void* stream) {
     XM3D_REQUIRE(rows >= 0 && C >= 4 && C % 4 == 0 && C <= 1024, "add_layer_norm: rows=%lld, C=%d (multiple of 4, <= 1024) expected", (long long)rows, C);
     if (rows == 0) return XM3D_OK;
     XM3D_REQUIRE(x && (y || y_bf || ypos_bf), "add_layer_norm: null pointer");
-    XM3D_REQUIRE((delta_dtype == 0 || delta_dtype == 1) && (pos_dtype == 0 || pos_dtype == 1), "add_layer_norm: dtype codes are 0 (f32) / 1 (bf16)");
+    XM3D_REQUIRE((delta_dtype == 0 || delta_dtype == 1) && (pos_dtype == 0 || pos_dtype == 1) && (out_dtype == 0 || out_dtype == 1),
+                 "add_layer_norm: dtype codes are 0 (f32) / 1 (bf16)");
+    XM3D_REQUIRE(out_dtype == 1 || ((reinterpret_cast<uintptr_t>(y_bf) | reinterpret_cast<uintptr_t>(ypos_bf)) & 15) == 0, "add_layer_norm: f32 outputs must be 16-byte aligned");
     XM3D_REQUIRE(!ypos_bf || (pos && pos_rows > 0), "add_layer_norm: ypos_bf needs pos and pos_rows > 0");
     XM3D_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(gamma) | reinterpret_cast<uintptr_t>(beta)) & 15) == 0 &&
                      ((reinterpret_cast<uintptr_t>(delta) | reinterpret_cast<uintptr_t>(pos) | reinterpret_cast<uintptr_t>(y_bf) | reinterpret_cast<uintptr_t>(ypos_bf)) & 7) == 0,
@@ -221,16 +231,22 @@ extern "C" int xm3d_add_layer_norm(const float* x, const void* delta, int32_t de
     hipStream_t s = as_stream(stream);
     const unsigned blocks = unsigned((rows + 3) / 4);
     typedef __hip_bfloat16 bf;
-#define XM3D_ALN(TD, TP)                                                                                                                            \
-    hipLaunchKernelGGL((k_add_layer_norm<TD, TP>), dim3(blocks), dim3(256), 0, s, x, static_cast<const TD*>(delta), gamma, beta, rows, C, eps,   \
-                       static_cast<const TP*>(pos), pos_rows, y, static_cast<bf*>(y_bf), static_cast<bf*>(ypos_bf))
+#define XM3D_ALN(TD, TP, TO)                                                                                                                        \
+    hipLaunchKernelGGL((k_add_layer_norm<TD, TP, TO>), dim3(blocks), dim3(256), 0, s, x, static_cast<const TD*>(delta), gamma, beta, rows, C, eps, \
+                       static_cast<const TP*>(pos), pos_rows, y, static_cast<TO*>(y_bf), static_cast<TO*>(ypos_bf))
+#define XM3D_ALN_O(TD, TP)            \
+    do {                              \
+        if (out_dtype == 0) XM3D_ALN(TD, TP, float); \
+        else XM3D_ALN(TD, TP, bf);    \
+    } while (0)
     if (delta_dtype == 0) {
-        if (pos_dtype == 0) XM3D_ALN(float, float);
-        else XM3D_ALN(float, bf);
+        if (pos_dtype == 0) XM3D_ALN_O(float, float);
+        else XM3D_ALN_O(float, bf);
     } else {
-        if (pos_dtype == 0) XM3D_ALN(bf, float);
-        else XM3D_ALN(bf, bf);
+        if (pos_dtype == 0) XM3D_ALN_O(bf, float);
+        else XM3D_ALN_O(bf, bf);
     }
+#undef XM3D_ALN_O
 #undef XM3D_ALN
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;

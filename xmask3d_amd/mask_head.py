@@ -73,16 +73,48 @@ class PositionEmbeddingSine(nn.Module):
         return torch.cat((pos_y, pos_x), dim=3).permute(0, 3, 1, 2)
 
 
+def _stream_mode(x):
+    """Inference over an f32 residual stream: the post-norm blocks below run as GEMMs (flinear) + ONE fused residual-add + LayerNorm launch per
+    block (ops.add_layer_norm) that also emits what the next GEMMs read - instead of cast + add + LayerNorm + add + casts.
+    "bf16" (autocast region of XMASK3d._decode_heads): the stream travels as (f32, bf16 copy, bf16 of stream + pos);
+    "f32" (the fp32 configuration, f32-accurate GEMMs): as (f32, the same f32 tensor, f32 stream + pos);  None: the plain path."""
+    if not (x.is_cuda and not torch.is_grad_enabled() and ops.add_layer_norm_supported(x, x.shape[-1]) and os.environ.get("XM3D_FUSED_LN", "hip") != "library"):
+        return None
+    if torch.is_autocast_enabled("cuda"):
+        return "bf16" if torch.get_autocast_dtype("cuda") == torch.bfloat16 else None
+    from .sd_model import gemm_f32_on
+
+    return "f32" if gemm_f32_on() else None
+
+
 def _bf16_stream_ok(x):
-    """bf16 inference (autocast region of XMASK3d._decode_heads) over an f32 residual stream: the post-norm blocks below then run as
-    bf16 GEMMs (flinear) + ONE fused residual-add + LayerNorm launch per block (ops.add_layer_norm) that also emits the bf16 copies the
-    next GEMMs read - instead of cast + add + LayerNorm + add + casts.  The stream travels as (f32, bf16, bf16 of stream + pos)."""
-    return (x.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled("cuda") and torch.get_autocast_dtype("cuda") == torch.bfloat16
-            and ops.add_layer_norm_supported(x, x.shape[-1]) and os.environ.get("XM3D_FUSED_LN", "hip") != "library")
+    return _stream_mode(x) == "bf16"
 
 
-def _add_ln(norm, x32, delta, pos=None, want=("f32", "bf16")):
-    return ops.add_layer_norm(x32, delta, norm.weight.float(), norm.bias.float(), norm.eps, pos=pos, want=want)
+_MODE_DTYPE = {"bf16": torch.bfloat16, "f32": torch.float32}
+
+
+def _add_ln(norm, x32, delta, pos=None, want=("f32", "bf16"), mode="bf16"):
+    w, b = norm.weight.float(), norm.bias.float()
+    if mode == "bf16":
+        return ops.add_layer_norm(x32, delta, w, b, norm.eps, pos=pos, want=want)
+    res = ops.add_layer_norm(x32, delta, w, b, norm.eps, pos=pos, want=tuple(k for k in want if k != "bf16"), out_dtype=torch.float32)
+    res = dict(zip((k for k in want if k != "bf16"), res if isinstance(res, tuple) else (res,)))
+    out = tuple(res["f32"] if k == "bf16" else res[k] for k in want)   # f32 mode: the "bf16 copy" is the stream itself
+    return out[0] if len(out) == 1 else out
+
+
+def _stream_attention(q4, k4, v4, bias, out_shape):
+    """flash attention on (B, L, H, d) views in the stream's dtype (bf16 kernel / f32-accurate kernel); None when neither takes the shapes"""
+    if ops.attention_supported(q4, k4, v4):
+        o = torch.empty(out_shape, dtype=q4.dtype, device=q4.device)
+        ops.attention(q4, k4, v4, bias=bias, out=o.view(out_shape[0], out_shape[1], q4.shape[2], q4.shape[3]).transpose(0, 1))
+        return o
+    if ops.attention_f32_supported(q4, k4, v4) and (bias is None or bias.dtype == torch.float32):
+        o = torch.empty(out_shape, dtype=torch.float32, device=q4.device)
+        ops.attention_f32(q4, k4, v4, bias=bias, out=o.view(out_shape[0], out_shape[1], q4.shape[2], q4.shape[3]).transpose(0, 1))
+        return o
+    return None
 
 
 # ----------------------------------------------------------------------------- pixel decoder
@@ -104,14 +136,14 @@ class MSDeformAttnTransformerEncoderLayer(nn.Module):
         src2 = self.linear2(self.dropout2(flinear(src, self.linear1.weight, self.linear1.bias, act="relu")))
         return self.norm2(src + self.dropout3(src2))
 
-    def forward_stream(self, st, pos, reference_points, spatial_shapes, level_start_index):
-        """bf16 inference on the (f32, bf16, bf16 + pos) stream: same arithmetic, 2 fused add + LayerNorm launches per layer"""
+    def forward_stream(self, st, pos, reference_points, spatial_shapes, level_start_index, mode):
+        """inference on the (f32, copy, copy + pos) stream (_stream_mode): same arithmetic, 2 fused add + LayerNorm launches per layer"""
         src32, src_b, srcpos_b = st
         delta = self.self_attn(srcpos_b, reference_points, src_b, spatial_shapes, level_start_index, None)
-        src32, src_b = _add_ln(self.norm1, src32, delta.contiguous())
+        src32, src_b = _add_ln(self.norm1, src32, delta.contiguous(), mode=mode)
         h = flinear(src_b, self.linear1.weight, self.linear1.bias, act="relu")
         delta = flinear(h, self.linear2.weight, self.linear2.bias)
-        return _add_ln(self.norm2, src32, delta.contiguous(), pos=pos, want=("f32", "bf16", "pos"))
+        return _add_ln(self.norm2, src32, delta.contiguous(), pos=pos, want=("f32", "bf16", "pos"), mode=mode)
 
 
 class MSDeformAttnTransformerEncoder(nn.Module):
@@ -135,12 +167,13 @@ class MSDeformAttnTransformerEncoder(nn.Module):
     def forward(self, src, spatial_shapes_list, spatial_shapes, level_start_index, valid_ratios, pos):
         ref = self.get_reference_points(spatial_shapes_list, valid_ratios, src.device)
         out = src
-        src32 = src.float().contiguous() if (src.is_cuda and not torch.is_grad_enabled() and torch.is_autocast_enabled("cuda")) else None
-        if src32 is not None and _bf16_stream_ok(src32) and pos.shape == src.shape and all(l.linear1.weight.dtype == torch.bfloat16 for l in self.layers):
-            pos = pos.contiguous()
-            st = (src32, src32.to(torch.bfloat16), (src32 + pos).to(torch.bfloat16))
+        src32 = src.float().contiguous() if (src.is_cuda and not torch.is_grad_enabled()) else None
+        mode = _stream_mode(src32) if src32 is not None else None
+        if mode is not None and pos.shape == src.shape and all(l.linear1.weight.dtype == _MODE_DTYPE[mode] for l in self.layers):
+            pos = pos.float().contiguous()
+            st = (src32, src32.to(torch.bfloat16), (src32 + pos).to(torch.bfloat16)) if mode == "bf16" else (src32, src32, src32 + pos)
             for layer in self.layers:
-                st = layer.forward_stream(st, pos, ref, spatial_shapes, level_start_index)
+                st = layer.forward_stream(st, pos, ref, spatial_shapes, level_start_index, mode)
             return st[0]
         for layer in self.layers:
             out = layer(out, pos, ref, spatial_shapes, level_start_index, None)
@@ -367,8 +400,8 @@ class SelfAttentionLayer(nn.Module):
             return self.norm(tgt + _mha_train(mha, q, k, tgt))
         return self.norm(tgt + self.self_attn(q, k, value=tgt, need_weights=False)[0])
 
-    def forward_stream(self, st, query_pos):
-        """bf16 inference on the (f32, bf16, bf16 + query_pos) stream; None when the flash-attention kernel does not take the shapes"""
+    def forward_stream(self, st, query_pos, mode):
+        """inference on the (f32, copy, copy + query_pos) stream; None when no flash-attention kernel takes the shapes"""
         tgt32, tgt_b, tgtpos_b = st
         mha = self.self_attn
         E, H = mha.embed_dim, mha.num_heads
@@ -379,12 +412,11 @@ class SelfAttentionLayer(nn.Module):
         q4 = qk[..., :E].unflatten(-1, (H, E // H)).transpose(0, 1)
         k4 = qk[..., E:].unflatten(-1, (H, E // H)).transpose(0, 1)
         v4 = v.view(L, B, H, E // H).transpose(0, 1)
-        if not ops.attention_supported(q4, k4, v4):
+        o = _stream_attention(q4, k4, v4, None, (L, B, E))
+        if o is None:
             return None
-        o = torch.empty((L, B, E), dtype=q4.dtype, device=tgt_b.device)
-        ops.attention(q4, k4, v4, out=o.view(L, B, H, E // H).transpose(0, 1))
         delta = flinear(o, mha.out_proj.weight, mha.out_proj.bias)
-        return _add_ln(self.norm, tgt32, delta, pos=query_pos, want=("f32", "bf16", "pos"))
+        return _add_ln(self.norm, tgt32, delta, pos=query_pos, want=("f32", "bf16", "pos"), mode=mode)
 
 
 class CrossAttentionLayer(nn.Module):
@@ -433,9 +465,9 @@ class CrossAttentionLayer(nn.Module):
         tgt2 = flinear(o.permute(2, 0, 1, 3).reshape(Lq, B, E), mha.out_proj.weight, mha.out_proj.bias)
         return self.norm(tgt + tgt2)
 
-    def forward_stream(self, st, memory_b, key_b, memory_bias, query_pos):
-        """bf16 inference on the (f32, bf16, bf16 + query_pos) stream; memory_b / key_b: contiguous bf16 (Lk, B, E) copies of the level's
-        memory and memory + pos (made once per level, three layers read each).  None when the flash-attention kernel does not apply."""
+    def forward_stream(self, st, memory_b, key_b, memory_bias, query_pos, mode):
+        """inference on the (f32, copy, copy + query_pos) stream; memory_b / key_b: contiguous (Lk, B, E) copies of the level's memory and
+        memory + pos in the stream's GEMM dtype (made once per level, three layers read each).  None when no flash-attention kernel applies."""
         tgt32, tgt_b, tgtpos_b = st
         mha = self.multihead_attn
         E, H = mha.embed_dim, mha.num_heads
@@ -446,12 +478,11 @@ class CrossAttentionLayer(nn.Module):
         Lq, B = q.shape[:2]
         Lk = k.shape[0]
         q4, k4, v4 = (t.view(t.shape[0], B, H, E // H).transpose(0, 1) for t in (q, k, v))
-        if not ops.attention_supported(q4, k4, v4):
+        o = _stream_attention(q4, k4, v4, memory_bias.view(B, 1, Lq, Lk), (Lq, B, E))
+        if o is None:
             return None
-        o = torch.empty((Lq, B, E), dtype=q.dtype, device=q.device)
-        ops.attention(q4, k4, v4, bias=memory_bias.view(B, 1, Lq, Lk), out=o.view(Lq, B, H, E // H).transpose(0, 1))
         delta = flinear(o, mha.out_proj.weight, mha.out_proj.bias)
-        return _add_ln(self.norm, tgt32, delta, pos=query_pos, want=("f32", "bf16", "pos"))
+        return _add_ln(self.norm, tgt32, delta, pos=query_pos, want=("f32", "bf16", "pos"), mode=mode)
 
 
 class FFNLayer(nn.Module):
@@ -467,11 +498,11 @@ class FFNLayer(nn.Module):
     def forward(self, tgt):
         return self.norm(tgt + self.linear2(flinear(tgt, self.linear1.weight, self.linear1.bias, act="relu")).float())
 
-    def forward_stream(self, st, query_pos):
+    def forward_stream(self, st, query_pos, mode):
         tgt32, tgt_b, _ = st
         h = flinear(tgt_b, self.linear1.weight, self.linear1.bias, act="relu")
         delta = flinear(h, self.linear2.weight, self.linear2.bias)
-        return _add_ln(self.norm, tgt32, delta, pos=query_pos, want=("f32", "bf16", "pos"))
+        return _add_ln(self.norm, tgt32, delta, pos=query_pos, want=("f32", "bf16", "pos"), mode=mode)
 
 
 class MLP(nn.Module):
@@ -603,19 +634,21 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
         c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[0], not skip)
         cls_l.append(c), mask_l.append(m), extra_l.append(e)
         st = mem_b = key_b = None
-        if attn_mask.dtype != torch.bool and _bf16_stream_ok(output) and self.transformer_ffn_layers[0].linear1.weight.dtype == torch.bfloat16:
+        mode = _stream_mode(output) if attn_mask.dtype != torch.bool else None
+        if mode is not None and self.transformer_ffn_layers[0].linear1.weight.dtype == _MODE_DTYPE[mode]:
             query_embed = query_embed.contiguous()
-            st = (output, output.to(torch.bfloat16), (output + query_embed).to(torch.bfloat16))
-            mem_b = [s_.to(torch.bfloat16).contiguous() for s_ in src]    # once per level: three layers read each
-            key_b = [k_.to(torch.bfloat16).contiguous() for k_ in keys]
+            dt = _MODE_DTYPE[mode]
+            st = (output, output.to(dt), (output + query_embed).to(dt))
+            mem_b = [s_.to(dt).contiguous() for s_ in src]    # once per level: three layers read each
+            key_b = [k_.to(dt).contiguous() for k_ in keys]
         for i in range(self.num_layers):
             lvl = i % self.num_feature_levels
             if st is not None and attn_mask.dtype != torch.bool:
                 # bf16 inference: the layer triple on the (f32, bf16, bf16 + query_pos) stream - one fused add + LayerNorm per block
-                s1 = self.transformer_cross_attention_layers[i].forward_stream(st, mem_b[lvl], key_b[lvl], attn_mask, query_embed)
-                s2 = self.transformer_self_attention_layers[i].forward_stream(s1, query_embed) if s1 is not None else None
+                s1 = self.transformer_cross_attention_layers[i].forward_stream(st, mem_b[lvl], key_b[lvl], attn_mask, query_embed, mode)
+                s2 = self.transformer_self_attention_layers[i].forward_stream(s1, query_embed, mode) if s1 is not None else None
                 if s2 is not None:
-                    st = self.transformer_ffn_layers[i].forward_stream(s2, query_embed)
+                    st = self.transformer_ffn_layers[i].forward_stream(s2, query_embed, mode)
                     output = st[0]
                     c, m, attn_mask, e = self.forward_prediction_heads(output, mask_features, size_list[(i + 1) % self.num_feature_levels],
                                                                        not skip or i == self.num_layers - 1)
@@ -646,9 +679,10 @@ class ODISEMultiScaleMaskedTransformerDecoder(nn.Module):
         return out
 
     def forward_prediction_heads(self, output, mask_features, attn_mask_target_size, with_embed=True):
-        if _bf16_stream_ok(output) and self.mask_embed.layers[0].weight.dtype == torch.bfloat16:
-            # bf16 inference: the fused LayerNorm hands the f32 rows (pooled-embedding residual) and their bf16 copy (the GEMMs' input)
-            dec32, dec_b = _add_ln(self.decoder_norm, output, None)
+        hmode = _stream_mode(output)
+        if hmode is not None and self.mask_embed.layers[0].weight.dtype == _MODE_DTYPE[hmode]:
+            # inference: the fused LayerNorm hands the f32 rows (pooled-embedding residual) and the GEMMs' input (bf16 copy / the same f32 rows)
+            dec32, dec_b = _add_ln(self.decoder_norm, output, None, mode=hmode)
             decoder_output, dec_in = dec32.transpose(0, 1), dec_b.transpose(0, 1).contiguous()
         else:
             decoder_output = dec_in = self.decoder_norm(output).transpose(0, 1)

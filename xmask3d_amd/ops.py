@@ -1139,10 +1139,11 @@ def add_layer_norm_supported(x, C):
             and C <= 1024)
 
 
-def add_layer_norm(x, delta, weight, bias, eps=1e-5, pos=None, want=("f32", "bf16")):
+def add_layer_norm(x, delta, weight, bias, eps=1e-5, pos=None, want=("f32", "bf16"), out_dtype=torch.bfloat16):
     """LayerNorm(x + delta) over the last dimension of the contiguous f32 stream x; delta f32 / bf16 like x, or None; weight / bias f32.
     want: which forms to return, in order - "f32" (the new stream), "bf16" (its bf16 rounding), "pos" (bf16(y + pos); pos f32 / bf16
-    whose rows repeat along the rows of x: the trailing rows.numel / C rows of x line up with pos)."""
+    whose rows repeat along the rows of x: the trailing rows.numel / C rows of x line up with pos).  out_dtype = torch.float32: "pos" comes
+    back as f32 (y + pos, the fp32 configuration) and "bf16" is not available."""
     C = x.shape[-1]
     if not (x.is_cuda and x.dtype == torch.float32 and x.is_contiguous() and C % 4 == 0 and C <= 1024):
         raise TypeError("add_layer_norm: contiguous f32 device tensor with C % 4 == 0, C <= 1024 required")
@@ -1159,12 +1160,15 @@ def add_layer_norm(x, delta, weight, bias, eps=1e-5, pos=None, want=("f32", "bf1
         prow = pos.numel() // C
         if prow == 0 or rows % prow:
             raise TypeError("add_layer_norm: the rows of pos must tile the rows of x")
+    if out_dtype not in (torch.bfloat16, torch.float32) or (out_dtype == torch.float32 and "bf16" in want):
+        raise TypeError("add_layer_norm: out_dtype bf16, or f32 without the \"bf16\" output")
     outs = {"f32": torch.empty_like(x) if "f32" in want else None,
             "bf16": torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if "bf16" in want else None,
-            "pos": torch.empty(x.shape, dtype=torch.bfloat16, device=x.device) if "pos" in want else None}
+            "pos": torch.empty(x.shape, dtype=out_dtype, device=x.device) if "pos" in want else None}
     check(lib().xm3d_add_layer_norm(_ptr(x), _ptr(delta), int(delta is not None and delta.dtype == torch.bfloat16), rows, C, _ptr(weight), _ptr(bias),
                                     float(eps), _ptr(pos) if "pos" in want else None, int(pos is not None and pos.dtype == torch.bfloat16), prow,
-                                    _ptr(outs["f32"]), _ptr(outs["bf16"]), _ptr(outs["pos"]), _stream()), "xm3d_add_layer_norm")
+                                    _ptr(outs["f32"]), _ptr(outs["bf16"]), _ptr(outs["pos"]), int(out_dtype == torch.bfloat16), _stream()),
+          "xm3d_add_layer_norm")
     res = tuple(outs[k] for k in want)
     return res[0] if len(res) == 1 else res
 
