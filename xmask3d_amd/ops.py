@@ -727,6 +727,9 @@ def gemm_pack_weight(weight, act=None):
     return packed, tile
 
 
+_GEMM_WAVES = int(_os.environ.get("XM3D_GEMM_WAVES", "0"))  # A/B switch for bench runs: force one workgroup geometry on every plain GEMM (0 = per-shape choice)
+
+
 def gemm(x, packed, n_rows, tile, bias=None, act=None, residual=None, waves=0):
     """out = act(x @ W^T + bias) (+ residual) over the last dimension of x; "geglu": out = (x Wv^T + bv) * GELU(x Wg^T + bg) with
     W = [Wv; Wg] (n_rows = 2 * out features).  x (..., K) bf16, bias f32 (n_rows) or None, residual like the output or None.
@@ -736,6 +739,8 @@ def gemm(x, packed, n_rows, tile, bias=None, act=None, residual=None, waves=0):
     if rows is None or k % 64 != 0:
         raise TypeError(f"gemm: unsupported input {tuple(x.shape)} {x.dtype} strides {x.stride()}")
     m, ldx = rows
+    if waves == 0 and _GEMM_WAVES and act != "geglu":
+        waves = _GEMM_WAVES
     a = GEMM_ACTS[act]
     nout = n_rows // 2 if a == 3 else n_rows
     out = torch.empty(x.shape[:-1] + (nout,), dtype=torch.bfloat16, device=x.device)
