@@ -324,13 +324,15 @@ def test_training_iteration_matches_the_cpu_oracle(dev, monkeypatch):
     for rep, v in enumerate((view, 0, 3)):
         b = batch if rep == 0 else pipeline.build_train_batch(sd, [v], vox, seed=11 + rep)
         grads = []
-        for m in (gpu, graphed):
-            for p in m.parameters():
+        for m in (gpu, graphed, gpu):   # the eager model twice: its own run-to-run spread (the library's weight-gradient kernels and the sparse
+            for p in m.parameters():    # nets' f32 atomics are not reproducible) is the yardstick for the comparison
                 p.grad = None
             monkeypatch.setattr(criterion, "_rand", seeded_rand())
             losses_m, _ = m(b)
             sum(losses_m.values()).backward()
             grads.append(({k: float(x) for k, x in losses_m.items()}, {n: p.grad for n, p in m.named_parameters() if p.grad is not None}))
+        noise = {n: float((grads[2][1][n] - grads[0][1][n]).abs().max()) / max(float(grads[0][1][n].abs().max()), 1e-12) for n in grads[0][1]}
+        grads = grads[:2]
         (le, ge), (lg, gg) = grads
         for k in sorted(le):
             assert abs(lg[k] - le[k]) / max(abs(le[k]), 1e-6) < 1e-4, (rep, k, lg[k], le[k])
@@ -344,9 +346,11 @@ def test_training_iteration_matches_the_cpu_oracle(dev, monkeypatch):
             # the sparse nets (eager in both runs) accumulate their weight gradients with f32 atomics: run-to-run noise of that size
             # (a gradient a replay got wrong is off by O(1) or by many orders of magnitude; the convolutions' weight gradients carry the
             # library's algorithm choice, measured up to 2.4e-3)
-            tol = 5e-2 if (n.startswith("pc_") or "alpha" in n or "clip_project" in n or "time_embed" in n) else 1e-2
+            tol = (5e-2 if (n.startswith("pc_") or "alpha" in n or "clip_project" in n or "time_embed" in n) else 1e-2) + 3 * noise[n]
             if not rel < tol:
-                bad.append((n, rel, ref))
+                bad.append((n, rel, ref, noise[n]))
         assert not bad, (rep, v, len(bad), sorted(bad, key=lambda t: -t[1])[:12])
-        print(f"[train graphs pass {rep} view {v}] {len(ge)} parameter gradients, worst relative difference to eager {worst[1]:.2e} ({worst[0]})")
+        nw = max(noise, key=noise.get)
+        print(f"[train graphs pass {rep} view {v}] {len(ge)} parameter gradients, worst relative difference to eager {worst[1]:.2e} ({worst[0]}); "
+              f"eager vs eager on the same batch: worst {noise[nw]:.2e} ({nw}), {worst[0]}: {noise[worst[0]]:.2e}")
     assert graphed._head_graphs is None and graphed.backbone.feature_extractor.ldm_extractor._vae_graphs
