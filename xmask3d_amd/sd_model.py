@@ -233,9 +233,17 @@ def _gn_f32(norm):
     return c[1], c[2]
 
 
+_GN_SEPARATE = int(os.environ.get("XM3D_CONV_GN_SEPARATE", "0"))
+
+
 def gn_silu_conv3x3(norm, conv, x, pend=None, bias=None, residual=None):
     """conv(SiLU(norm(x + pend))) + bias (+ residual) in one launch; bias None = the convolution's own.  The moments of x come from
     the kernel that produced it when it left them on the tensor, and the moments of the result are left on it for the next norm."""
+    if _GN_SEPARATE and pend is None and x.dtype == torch.bfloat16 and x.shape[1] >= _GN_SEPARATE:
+        # A/B (XM3D_CONV_GN_SEPARATE=<min cin>): the normalisation as its own apply pass (moments from the producer's epilogue) + the plain kernel
+        packed, tile, own_bias = _packed(conv)
+        return ops.conv3x3(gn_act(norm, x, ACT_SILU), packed, conv.out_channels, tile, bias=own_bias if bias is None else bias, residual=residual,
+                           stats_groups=32 if (conv.out_channels // 32) % 4 == 0 else None)
     gamma, beta = _gn_f32(norm)
     stats = ops.gn_stats_of(x, norm.num_groups, shift=pend)
     if x.dtype == torch.float32:
