@@ -19,6 +19,8 @@ each scene reads its own slice, so a batch of B views gives exactly the B batch-
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -341,7 +343,8 @@ class XMASK3d(nn.Module):
     def front_stream(self):
         """The stream `pipeline.infer_scene` runs the NEXT scene's front on (voxelisation, sparse 3D nets)."""
         if getattr(self, "_front_stream", None) is None:
-            self._front_stream = torch.cuda.Stream()
+            # XM3D_FRONT_PRIORITY=1: a high-priority queue for the front's ~1000 small kernels (A/B switch)
+            self._front_stream = torch.cuda.Stream(priority=-1) if os.environ.get("XM3D_FRONT_PRIORITY", "0") == "1" else torch.cuda.Stream()
         return self._front_stream
 
     # ------------------------------------------------------------------ forward
@@ -378,9 +381,10 @@ class XMASK3d(nn.Module):
             with torch.cuda.stream(stream):
                 if tail is not None:
                     stream.wait_event(tail)
-                if graphed:
+                if graphed and os.environ.get("XM3D_FRONT_PARALLEL", "0") != "1":
                     # the sparse front queues up behind this forward's VAE-encoder graph: when both run beside graph C
                     # at once the front's small kernels starve (30 -> 100 ms at 20 views) and delay the next graph B
+                    # (XM3D_FRONT_PARALLEL=1: A/B switch, issue it beside the encoder graph)
                     stream.wait_stream(g["side"])
                 self.mark("S0", stream)
                 front["pred_3d"], front["cond"], front["binary_scores"] = self.encode_3d(sinput, inds, B)
