@@ -404,6 +404,22 @@ def infer_scene(model, sd: SceneOnDevice, cfg, voxelizer=None, matrices=None, wi
     return result
 
 
+# XM3D_MAIN_STREAMS=2 (A/B switch): consecutive forwards alternate between two main streams, so that the convolution-bound graph B of forward
+# i + 1 can start as soon as its front is done - beside the latency-bound graph C, fusion and post-processing of forward i - instead of behind them
+_MAIN_STREAMS = int(os.environ.get("XM3D_MAIN_STREAMS", "1"))
+
+
+def _main_stream(model, caller):
+    st = model.__dict__.setdefault("_main_streams", None)
+    if st is None:
+        st = model.__dict__["_main_streams"] = [torch.cuda.Stream(), torch.cuda.Stream()]
+        for x in st:
+            x.wait_stream(caller)  # once: everything the caller prepared before the first forward (weights, scene data)
+        model.__dict__["_main_turn"] = 0
+    model.__dict__["_main_turn"] ^= 1
+    return st[model.__dict__["_main_turn"]]
+
+
 @torch.no_grad()
 def infer_scenes(model, sds, cfg, voxelizer=None, matrices=None, with_ablations=True, next_scenes=None, next_matrices=None):
     """infer_scene for a GROUP of scenes whose views all go through ONE forward (e.g. 2 scenes x 5 views = batch 10): the
@@ -424,23 +440,39 @@ def infer_scenes(model, sds, cfg, voxelizer=None, matrices=None, with_ablations=
         return a is not None and b is not None and len(a) == len(b) and all(x is y for x, y in zip(a, b))
 
     pending, model._next_front = getattr(model, "_next_front", None), None
-    if pending is not None and same(pending.get("scenes"), sds) and pending["matrices"] is matrices:
-        batch, front = pending["batch"], pending["front"]
-    else:
-        batch = build_group_batch([(sd, list(range(len(sd.views)))) for sd in sds], voxelizer, matrices)
-        batch["compact_outputs"] = False
-        front = model.eval_front(batch)
-    outputs = model.eval_fuse(batch, front, model.eval_dense(batch, front))
-    model.mark("F1")
-    preds = postprocess_scene(cfg, outputs, batch, with_ablations)
-    # votes of all views of all scenes, first-max label per scene point and the "seen" flags: two launches (xm3d_scene_votes)
-    rb = batch["vote_row_base"]
-    label, seen = ops.scene_votes(batch["vote_rows"], torch.stack([p for p in preds if p is not None]), rb[-1], ncls)
-    results = []
-    for j, sd in enumerate(sds):
-        fill = nearest_valid_fill(sd.points_f32, seen[rb[j]:rb[j + 1]])  # unseen points take the nearest seen point's label
-        results.append([label[k, rb[j]:rb[j + 1]][fill] for k in range(label.shape[0])] + [None] * (3 - label.shape[0]))
-    model.mark("P1")
+    caller = torch.cuda.current_stream()
+    ms = _main_stream(model, caller) if _MAIN_STREAMS == 2 else caller
+    with torch.cuda.stream(ms):
+        if pending is not None and same(pending.get("scenes"), sds) and pending["matrices"] is matrices:
+            batch, front = pending["batch"], pending["front"]
+        else:
+            batch = build_group_batch([(sd, list(range(len(sd.views)))) for sd in sds], voxelizer, matrices)
+            batch["compact_outputs"] = False
+            front = model.eval_front(batch)
+        dense = model.eval_dense(batch, front)
+        prev = getattr(model, "_main_done", None)
+        if ms is not caller and prev is not None:
+            ms.wait_event(prev)  # the eager stages of consecutive forwards share cached workspaces: fusion i + 1 starts after post-processing i
+        outputs = model.eval_fuse(batch, front, dense)
+        model.mark("F1")
+        preds = postprocess_scene(cfg, outputs, batch, with_ablations)
+        # votes of all views of all scenes, first-max label per scene point and the "seen" flags: two launches (xm3d_scene_votes)
+        rb = batch["vote_row_base"]
+        label, seen = ops.scene_votes(batch["vote_rows"], torch.stack([p for p in preds if p is not None]), rb[-1], ncls)
+        results = []
+        for j, sd in enumerate(sds):
+            fill = nearest_valid_fill(sd.points_f32, seen[rb[j]:rb[j + 1]])  # unseen points take the nearest seen point's label
+            results.append([label[k, rb[j]:rb[j + 1]][fill] for k in range(label.shape[0])] + [None] * (3 - label.shape[0]))
+        model.mark("P1")
+        if ms is not caller:
+            model._main_done = torch.cuda.Event()
+            model._main_done.record(ms)
+    if ms is not caller:  # the caller reads the labels on its own stream
+        caller.wait_event(model._main_done)
+        for r in results:
+            for t in r:
+                if t is not None:
+                    t.record_stream(caller)
     if next_scenes is not None:
         nxt = list(next_scenes)
         fs = model.front_stream()
