@@ -54,3 +54,20 @@ def test_positional_embedding_cache_is_device_only_and_values_match():
     a = pe(torch.zeros(2, 8, 6, 5))
     b = pe._compute(2, 6, 5, torch.device("cpu"), None)
     assert torch.equal(a, b) and "_pe_cache" not in pe.__dict__         # CPU calls never populate the cache
+
+
+def test_sdpa_backend_switch_is_documented_and_reversible():
+    """importing the package switches torch's Triton-built SDPA backends off process-wide (no Triton on this path); a host application
+    can take torch's defaults back"""
+    import xmask3d_amd
+
+    flash, mem = torch.backends.cuda.flash_sdp_enabled(), torch.backends.cuda.mem_efficient_sdp_enabled()
+    try:
+        xmask3d_amd._no_triton_attention()
+        assert not torch.backends.cuda.flash_sdp_enabled() and not torch.backends.cuda.mem_efficient_sdp_enabled()
+        assert torch.backends.cuda.math_sdp_enabled()
+        xmask3d_amd.restore_sdpa_defaults()
+        assert torch.backends.cuda.flash_sdp_enabled() and torch.backends.cuda.mem_efficient_sdp_enabled()
+    finally:
+        torch.backends.cuda.enable_flash_sdp(flash)
+        torch.backends.cuda.enable_mem_efficient_sdp(mem)

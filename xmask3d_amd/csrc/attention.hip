@@ -26,6 +26,7 @@ namespace xm3d {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4a __attribute__((ext_vector_type(4)));
+typedef float f32x2a __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8a __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4a __attribute__((ext_vector_type(4)));
 
@@ -190,16 +191,26 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
         float psum = 0.f;
         bf16x8a pf[2][2];
         if (plain) {
+            // score pairs through the packed f32 pipe (v_pk_fma_f32 / v_pk_add_f32: two scores per issue slot) - this loop is
+            // VALU-bound for the 40-channel heads (32 scores per lane and tile against 14 MFMAs per wave)
+            const f32x2a sc2 = {scale_log2e, scale_log2e}, nm2 = {-m_new, -m_new};
+            f32x2a ps2 = {0.f, 0.f};
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
                 for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {
-                        const float p = __builtin_amdgcn_exp2f(fmaf(sacc[kb][8 * s2 + j], scale_log2e, -m_new));  // bare v_exp_f32: the argument is <= 0, a denormal result may flush
-                        psum += p;
-                        pf[kb][s2][j] = (__bf16)p;
+                    for (int j = 0; j < 8; j += 2) {
+                        const f32x2a sv = {sacc[kb][8 * s2 + j], sacc[kb][8 * s2 + j + 1]};
+                        const f32x2a e = __builtin_elementwise_fma(sv, sc2, nm2);
+                        f32x2a p;
+                        p[0] = __builtin_amdgcn_exp2f(e[0]);  // bare v_exp_f32: the argument is <= 0, a denormal result may flush
+                        p[1] = __builtin_amdgcn_exp2f(e[1]);
+                        ps2 += p;
+                        pf[kb][s2][j] = (__bf16)p[0];
+                        pf[kb][s2][j + 1] = (__bf16)p[1];
                     }
+            psum = ps2[0] + ps2[1];
         } else {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)

@@ -18,6 +18,7 @@
 namespace xm3d {
 
 typedef float af_f32x16 __attribute__((ext_vector_type(16)));
+typedef float af_f32x2 __attribute__((ext_vector_type(2)));
 typedef _Float16 af_f16x8 __attribute__((ext_vector_type(8)));
 
 constexpr int AF_NW = 4;      // waves per workgroup (32 query rows each)
@@ -169,7 +170,22 @@ __global__ __launch_bounds__(64 * AF_NW) void k_attn_fwd_f32acc(
                 sb = __builtin_amdgcn_mfma_f32_32x32x16_f16(kfh, qh[s], sb, 0, 0, 0);
             }
             // ---- scale, bias, key bound; running maximum (log2 domain)
+            // whole unmasked blocks take the short path: pairs of scores through the packed f32 pipe (v_pk_fma_f32 / v_pk_add_f32),
+            // the maximum on the unscaled scores (scale > 0), no key-bound / mask tests
+            const bool plain = BIAS == 0 && kbase + 32 <= Nk;  // wave-uniform
             float mx = AF_NEG;
+            if (plain) {
+                const af_f32x2 il2 = {AF_INV_LO, AF_INV_LO};
+#pragma unroll
+                for (int r = 0; r < 16; r += 2) {
+                    const af_f32x2 s2v = {ss[r], ss[r + 1]}, sbv = {sb[r], sb[r + 1]};
+                    const af_f32x2 tv2 = __builtin_elementwise_fma(s2v, il2, sbv);
+                    sb[r] = tv2[0];
+                    sb[r + 1] = tv2[1];
+                    mx = fmaxf(mx, fmaxf(tv2[0], tv2[1]));
+                }
+                mx *= sc2;
+            } else
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * h;
@@ -190,6 +206,24 @@ __global__ __launch_bounds__(64 * AF_NW) void k_attn_fwd_f32acc(
             const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
             float psum = 0.f;
             af_f16x8 ph[2], pl[2];
+            if (plain) {
+                const af_f32x2 scv = {sc2, sc2}, nm2 = {-m_new, -m_new};
+                af_f32x2 ps2 = {0.f, 0.f};
+#pragma unroll
+                for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) {
+                        const af_f32x2 sv = {sb[8 * s2 + j], sb[8 * s2 + j + 1]};
+                        const af_f32x2 e = __builtin_elementwise_fma(sv, scv, nm2);
+                        af_f32x2 p;
+                        p[0] = __builtin_amdgcn_exp2f(e[0]);
+                        p[1] = __builtin_amdgcn_exp2f(e[1]);
+                        ps2 += p;
+                        AF_SPLIT(p[0], ph[s2][j], pl[s2][j]);
+                        AF_SPLIT(p[1], ph[s2][j + 1], pl[s2][j + 1]);
+                    }
+                psum = ps2[0] + ps2[1];
+            } else
 #pragma unroll
             for (int s2 = 0; s2 < 2; ++s2)
 #pragma unroll
