@@ -20,6 +20,8 @@
 //     second product O^T += V^T P^T for k-step s (same k-slot permutation on both operands); the A operand V^T comes out
 //     of the row-major V tile through the hardware transposing LDS read ds_read_b64_tr_b16
 //   * exp2 with the scale folded into one fma per score; fully masked rows give zeros
+#include <type_traits>
+
 #include "common.h"
 
 namespace xm3d {
@@ -68,6 +70,13 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
     constexpr int VLD = DV + 8;
     __shared__ __attribute__((aligned(16))) __bf16 lk[2][ATT_KV][KLD];
     __shared__ __attribute__((aligned(16))) __bf16 lv[2][ATT_KV][VLD];
+    // additive bias: the accumulator layout has the QUERY on the lane and the keys in registers, so reading bias[q][key] at the point
+    // of use made every load instruction touch 64 rows (64 cache lines for 128 bytes of payload: mask-CLIP's 307 x 307 attention ran
+    // 3.3 x slower with its mask than without).  Each wave instead fetches its 32 x 64 block row by row with the KEY on the lane
+    // (one or two lines per instruction) into a wave-private LDS tile and reads it back transposed, four consecutive keys per access.
+    using BiasT = std::conditional_t<BIAS == 1, float, __bf16>;
+    constexpr int BLD = ATT_KV + (BIAS == 1 ? 4 : 4);  // padded row: the 32 row-strided reads of a half-wave spread over the banks
+    __shared__ __attribute__((aligned(16))) BiasT lb[BIAS != 0 ? ATT_NW : 1][BIAS != 0 ? 32 : 1][BIAS != 0 ? BLD : 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -142,6 +151,17 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
     for (int t = 0; t < ntiles; ++t) {
         const int buf = t & 1;
         if (t + 1 < ntiles) tile_load(t + 1);
+        // bias block of this wave and tile, KEY on the lane: requested before the score products, transposed through LDS behind them
+        BiasT braw[BIAS != 0 ? 32 : 1];
+        if constexpr (BIAS != 0) {
+            // row addresses are wave-uniform (scalar registers), the lane adds its key; rows past Nq / keys past Nk are clamped to the
+            // last valid one: their values are never used (the key bound below, no store for rows past Nq)
+            const int q0s = __builtin_amdgcn_readfirstlane(q0);
+            const BiasT* const bp = static_cast<const BiasT*>(bias) + b * b_sb + head * b_sh;
+            const int kl = min(t * ATT_KV + lane, Nk - 1);
+#pragma unroll
+            for (int i = 0; i < 32; ++i) braw[i] = bp[int64_t(min(q0s + i, Nq - 1)) * b_sq + kl];
+        }
         // ---- S^T = K Q^T for the two 32-key blocks of the tile
         f32x16 sacc[2];
 #pragma unroll
@@ -158,7 +178,13 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
         //      take the short path: max on the raw scores, one fma + one exp2 per score
         const int kbase = t * ATT_KV;
         const bool plain = BIAS == 0 && kbase + ATT_KV <= Nk;  // wave-uniform
+        if constexpr (BIAS != 0) {
+#pragma unroll
+            for (int i = 0; i < 32; ++i) lb[wave][i][lane] = braw[i];
+            __builtin_amdgcn_wave_barrier();  // wave-private tile; the LDS executes one wave's accesses in issue order
+        }
         float mx = ATT_NEG;
+        float bq4[4] = {0.f, 0.f, 0.f, 0.f};
         if (plain) {
 #pragma unroll
             for (int kb = 0; kb < 2; ++kb)
@@ -172,13 +198,20 @@ __global__ __launch_bounds__(64 * ATT_NW) void k_attn_fwd(
                 for (int r = 0; r < 16; ++r) {
                     const int key = kbase + 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * h;
                     float sc = sacc[kb][r] * scale_log2e;
-                    if (BIAS != 0) {
-                        const int q = q0 + l31;
-                        if (q < Nq && key < Nk) {
-                            const int64_t bo = b * b_sb + head * b_sh + int64_t(q) * b_sq + key;
-                            const float bv = BIAS == 1 ? static_cast<const float*>(bias)[bo] : float(static_cast<const __bf16*>(bias)[bo]);
-                            sc = bv < -1e29f ? ATT_NEG : sc + bv * 1.4426950408889634f;
+                    if constexpr (BIAS != 0) {  // (rows past Nq / keys past Nk hold clamped copies: the key bound follows)
+                        if ((r & 3) == 0) {     // the lane's four consecutive keys of this group: one 8- / 16-byte LDS read
+                            const BiasT* const src = &lb[wave][l31][32 * kb + 2 * r + 4 * h];
+                            if constexpr (BIAS == 1) {
+                                const float4 v4 = *reinterpret_cast<const float4*>(src);
+                                bq4[0] = v4.x, bq4[1] = v4.y, bq4[2] = v4.z, bq4[3] = v4.w;
+                            } else {
+                                const uint2 v2 = *reinterpret_cast<const uint2*>(src);
+                                bq4[0] = __uint_as_float(v2.x << 16), bq4[1] = __uint_as_float(v2.x & 0xFFFF0000u);
+                                bq4[2] = __uint_as_float(v2.y << 16), bq4[3] = __uint_as_float(v2.y & 0xFFFF0000u);
+                            }
                         }
+                        const float bv = bq4[r & 3];
+                        sc = bv < -1e29f ? ATT_NEG : fmaf(bv, 1.4426950408889634f, sc);
                     }
                     if (key >= Nk) sc = ATT_NEG;
                     sacc[kb][r] = sc;

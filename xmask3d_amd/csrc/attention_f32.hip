@@ -61,6 +61,10 @@ __global__ __launch_bounds__(64 * AF_NW) void k_attn_fwd_f32acc(
     constexpr int KLD = DQ + 8, VLD = DV + 8;  // padded LDS rows (halves)
     __shared__ __attribute__((aligned(16))) _Float16 lk[2][2][AF_KV][KLD];  // [buffer][hi | lo][key][channel]
     __shared__ __attribute__((aligned(16))) _Float16 lv[2][2][AF_KV][VLD];
+    // additive bias: the score accumulator has the QUERY on the lane and the keys in registers - read at the point of use, every load
+    // instruction touched 64 rows of the bias.  Each wave fetches its block with 8 keys x 8 rows per instruction (8 lines instead of
+    // 64) and transposes it through a wave-private LDS strip, 8 keys at a time (the K / V tiles leave 6 KB for two workgroups per CU).
+    __shared__ __attribute__((aligned(16))) float lb[BIAS != 0 ? AF_NW : 1][BIAS != 0 ? 32 : 1][BIAS != 0 ? 12 : 4];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, h = lane >> 5;
@@ -145,6 +149,11 @@ __global__ __launch_bounds__(64 * AF_NW) void k_attn_fwd_f32acc(
     float m_run = AF_NEG, l_run = 0.f;
     const float sc2 = scale_log2e * (1.f / (AF_SX * AF_SX));  // undoes the operand scales of Q and K
 
+    int64_t brow[BIAS != 0 ? 4 : 1];  // bias rows this lane fetches: 8 j + (lane >> 3), clamped to the last query (never used past it)
+    if constexpr (BIAS != 0) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) brow[j] = b * b_sb + head * b_sh + int64_t(min(q0 + 8 * j + (lane >> 3), Nq - 1)) * b_sq;
+    }
     const int ntiles = (Nk + AF_KV - 1) / AF_KV;
     tile_load(0);
     __syncthreads();  // zero fill done
@@ -157,6 +166,15 @@ __global__ __launch_bounds__(64 * AF_NW) void k_attn_fwd_f32acc(
         for (int kb = 0; kb < 2; ++kb) {
             const int kbase = t * AF_KV + 32 * kb;
             if (kbase >= Nk) continue;  // wave-uniform: a block past the end contributes nothing
+            float braw[BIAS != 0 ? 16 : 1];  // requested before the score products: group g = keys 8 g .. 8 g + 7 of the block
+            if constexpr (BIAS != 0) {
+#pragma unroll
+                for (int g = 0; g < 4; ++g) {
+                    const int kl = min(kbase + 8 * g + (lane & 7), Nk - 1);  // keys past Nk: clamped copies, masked by the key bound
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) braw[4 * g + j] = bias[brow[j] + kl];
+                }
+            }
             // ---- S^T = K Q^T for this 32-key block: leading and small terms
             af_f32x16 sb, ss;
 #pragma unroll
@@ -174,6 +192,7 @@ __global__ __launch_bounds__(64 * AF_NW) void k_attn_fwd_f32acc(
             // the maximum on the unscaled scores (scale > 0), no key-bound / mask tests
             const bool plain = BIAS == 0 && kbase + 32 <= Nk;  // wave-uniform
             float mx = AF_NEG;
+            float bq4[4] = {0.f, 0.f, 0.f, 0.f};
             if (plain) {
                 const af_f32x2 il2 = {AF_INV_LO, AF_INV_LO};
 #pragma unroll
@@ -190,12 +209,17 @@ __global__ __launch_bounds__(64 * AF_NW) void k_attn_fwd_f32acc(
             for (int r = 0; r < 16; ++r) {
                 const int key = kbase + (r & 3) + 8 * (r >> 2) + 4 * h;
                 float sc = fmaf(ss[r], AF_INV_LO, sb[r]) * sc2;
-                if (BIAS != 0) {
-                    const int q = q0 + l31;
-                    if (q < Nq && key < Nk) {
-                        const float bv = bias[b * b_sb + head * b_sh + int64_t(q) * b_sq + key];
-                        sc = bv < -1e29f ? AF_NEG : sc + bv * 1.4426950408889634f;
+                if constexpr (BIAS != 0) {
+                    if ((r & 3) == 0) {  // group r / 4 through the strip: rows on the lanes -> this lane's four consecutive keys
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) lb[wave][8 * j + (lane >> 3)][lane & 7] = braw[r + j];
+                        __builtin_amdgcn_wave_barrier();  // wave-private strip; the LDS executes one wave's accesses in issue order
+                        const float4 v4 = *reinterpret_cast<const float4*>(&lb[wave][l31][4 * h]);
+                        bq4[0] = v4.x, bq4[1] = v4.y, bq4[2] = v4.z, bq4[3] = v4.w;
+                        __builtin_amdgcn_wave_barrier();
                     }
+                    const float bv = bq4[r & 3];
+                    sc = bv < -1e29f ? AF_NEG : fmaf(bv, 1.4426950408889634f, sc);
                 }
                 if (key >= Nk) sc = AF_NEG;
                 sb[r] = sc;
