@@ -362,8 +362,10 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--views-per-batch", type=int, default=0, help="views per forward (0 = all views of the scene; 1 = reference loop)")
     ap.add_argument("--miopen-find", action="store_true", help="torch.backends.cudnn.benchmark=True (MIOpen find through the shipped find-db)")
-    ap.add_argument("--scenes-per-forward", type=int, default=4,
-                    help="scenes whose views share one forward (views are independent until the vote); 1 = one scene per forward")
+    ap.add_argument("--scenes-per-forward", type=int, default=5,
+                    help="scenes whose views share one forward (views are independent until the vote); 1 = one scene per forward.  "
+                         "5 (25 views): 43.2 scenes/s against 42.7 at 4 and 43.2 at 6 on one box after the round-4 attention kernels "
+                         "(profiles/r04_bench_scenes_per_forward_ab2.log); the driver's 20 steps are four whole groups of 5")
     ap.add_argument("--train-steps", type=int, default=8,
                     help="training iterations timed after the inference steps (1 view per GPU, DDP when --gpus > 1), reported under "
                          "\"train\" (fp32 as the reference trains, plus a bf16-frozen-nets run); 0 = skip")

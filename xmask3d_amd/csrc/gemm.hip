@@ -84,6 +84,29 @@ __device__ __forceinline__ float gm_gelu(float x) {
     return 0.5f * x * (1.f + copysignf(e, x));
 }
 
+// The same GELU for a PAIR of gates, arranged for the packed f32 pipe (v_pk_fma_f32 / v_pk_mul_f32: two values per issue slot) - the GEGLU
+// epilogue evaluates 64 of them per lane and, for the K = 320 / 640 layers of the UNet, costs more vector time than the K loop has MFMA
+// time.  With p(t) the A&S polynomial and q = p(t) 2^(-x^2 log2(e) / 2) / 2:   GELU(x) = x q + max(x, 0) (1 - 2 q)   (x >= 0: x - x q,
+// x < 0: x q), the same function as gm_gelu up to the rounding of the rearranged products.
+typedef float gm_f32x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ gm_f32x2 gm_gelu2(gm_f32x2 x) {
+    const gm_f32x2 ax = {fabsf(x[0]), fabsf(x[1])};
+    const gm_f32x2 d = __builtin_elementwise_fma(ax, gm_f32x2{0.3275911f * 0.70710678118654752f, 0.3275911f * 0.70710678118654752f}, gm_f32x2{1.f, 1.f});
+    const gm_f32x2 t = {__builtin_amdgcn_rcpf(d[0]), __builtin_amdgcn_rcpf(d[1])};
+    gm_f32x2 p = __builtin_elementwise_fma(t, gm_f32x2{0.5f * 1.061405429f, 0.5f * 1.061405429f}, gm_f32x2{0.5f * -1.453152027f, 0.5f * -1.453152027f});
+    p = __builtin_elementwise_fma(t, p, gm_f32x2{0.5f * 1.421413741f, 0.5f * 1.421413741f});
+    p = __builtin_elementwise_fma(t, p, gm_f32x2{0.5f * -0.284496736f, 0.5f * -0.284496736f});
+    p = __builtin_elementwise_fma(t, p, gm_f32x2{0.5f * 0.254829592f, 0.5f * 0.254829592f});
+    p = p * t;
+    const gm_f32x2 arg = (x * x) * gm_f32x2{-0.5f * 1.4426950408889634f, -0.5f * 1.4426950408889634f};
+    const gm_f32x2 ex = {__builtin_amdgcn_exp2f(arg[0]), __builtin_amdgcn_exp2f(arg[1])};
+    const gm_f32x2 q = p * ex;
+    const gm_f32x2 xq = x * q;
+    const gm_f32x2 rx = {fmaxf(x[0], 0.f), fmaxf(x[1], 0.f)};
+    const gm_f32x2 w = __builtin_elementwise_fma(q, gm_f32x2{-2.f, -2.f}, gm_f32x2{1.f, 1.f});
+    return __builtin_elementwise_fma(rx, w, xq);
+}
+
 // NW = 8: 512 threads, 256 token rows (one workgroup per CU).  NW = 4 (CT = 128 only): 256 threads, 128 token rows, a wave = one
 // 32-column block x all 128 rows; two to three workgroups per CU - the geometry for small M (M = 5 k rows x 256-row tiles leaves
 // the chip two thirds empty) and for overlapping one workgroup's prologue / epilogue with another's K loop
@@ -336,13 +359,24 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
                 if (a.residual && row < M) rr = *reinterpret_cast<const uint4*>(a.residual + int64_t(row) * a.ldr + col);
                 const unsigned rw[4] = {rr.x, rr.y, rr.z, rr.w};
 #pragma unroll
-                for (int i = 0; i < 8; ++i) {
-                    const float send = h ? acc[n][i] : acc[n][8 + i];  // h = 1 sends gates 0..7, h = 0 sends values 8..15
-                    const float recv = __shfl_xor(send, 32);
-                    const float val = (h ? recv : acc[n][i]) + bv[i];
-                    const float gate = (h ? acc[n][8 + i] : recv) + bg[i];
-                    const float res = __uint_as_float((i & 1) ? (rw[i >> 1] & 0xFFFF0000u) : (rw[i >> 1] << 16));
-                    pk[i] = (__bf16)(val * gm_gelu(gate) + res);
+                for (int i = 0; i < 8; i += 2) {
+                    gm_f32x2 val, gate;
+#pragma unroll
+                    for (int j = 0; j < 2; ++j) {
+                        // two STATIC register reads, laundered: `h ? acc[i] : acc[8 + i]` is otherwise canonicalised into one extract with a
+                        // run-time index, which hipcc lowers to a 16-way compare / select cascade (~30 vector instructions per element:
+                        // 1900 of them per tile row block, more than the whole K loop of the 320-channel layers)
+                        float lo = acc[n][i + j], hi = acc[n][8 + i + j];
+                        asm volatile("" : "+v"(lo), "+v"(hi));
+                        const float send = h ? lo : hi;  // h = 1 sends gates 0..7, h = 0 sends values 8..15
+                        const float recv = __shfl_xor(send, 32);
+                        val[j] = (h ? recv : lo) + bv[i + j];
+                        gate[j] = (h ? hi : recv) + bg[i + j];
+                    }
+                    const gm_f32x2 res = {__uint_as_float(rw[i >> 1] << 16), __uint_as_float(rw[i >> 1] & 0xFFFF0000u)};
+                    const gm_f32x2 o = __builtin_elementwise_fma(val, gm_gelu2(gate), res);
+                    pk[i] = (__bf16)o[0];
+                    pk[i + 1] = (__bf16)o[1];
                 }
                 if (row < M) *reinterpret_cast<gm_bf16x8*>(a.out + int64_t(row) * a.ldo + col) = pk;
             }

@@ -193,7 +193,7 @@ def infer(cfg, model=None, scenes=1, resume=None, dense_dtype=torch.bfloat16, lo
         if rank == 0:
             log(f"infer: {scenes} ScanNet scene(s) from {cfg.data_root} / {cfg.data_root_2d}")
     mine = list(range(rank, scenes, world))  # DistributedSampler(shuffle=False) partition
-    G = max(1, int(getattr(cfg, "scenes_per_forward", 4)))  # scenes whose views share one forward (pipeline.infer_scenes)
+    G = max(1, int(getattr(cfg, "scenes_per_forward", 5)))  # scenes whose views share one forward (pipeline.infer_scenes)
     chunks = [mine[i:i + G] for i in range(0, len(mine), G)]
 
     vox = pipeline.default_voxelizer(cfg.voxel_size, dev)
