@@ -727,6 +727,7 @@ def gemm_pack_weight(weight, act=None):
     return packed, tile
 
 
+_GEMM_WAVES_GEGLU = _os.environ.get("XM3D_GEMM_WAVES_GEGLU", "0") == "1"  # tuning runs: let XM3D_GEMM_WAVES also move the GEGLU launches
 _GEMM_WAVES = int(_os.environ.get("XM3D_GEMM_WAVES", "0"))  # A/B switch for bench runs: force one workgroup geometry on every plain GEMM (0 = per-shape choice)
 
 
@@ -739,7 +740,7 @@ def gemm(x, packed, n_rows, tile, bias=None, act=None, residual=None, waves=0):
     if rows is None or k % 64 != 0:
         raise TypeError(f"gemm: unsupported input {tuple(x.shape)} {x.dtype} strides {x.stride()}")
     m, ldx = rows
-    if waves == 0 and _GEMM_WAVES and act != "geglu":
+    if waves == 0 and _GEMM_WAVES and (act != "geglu" or _GEMM_WAVES_GEGLU):
         waves = _GEMM_WAVES
     a = GEMM_ACTS[act]
     nout = n_rows // 2 if a == 3 else n_rows
