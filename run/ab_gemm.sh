@@ -3,7 +3,7 @@
 set -e -o pipefail
 mkdir -p gpurun_out
 BASE=xmask3d_amd/ab/libxm3d_hip_base.so
-python -m pytest tests/test_gpu_gemm.py -q -x -m gpu > gpurun_out/ab_gemm_tests.log 2>&1 || { tail -30 gpurun_out/ab_gemm_tests.log; exit 1; }
+python -m pytest tests/test_gpu_gemm.py tests/test_gpu_f32acc.py tests/test_gpu_conv_gemm.py -q -x -m gpu > gpurun_out/ab_gemm_tests.log 2>&1 || { tail -30 gpurun_out/ab_gemm_tests.log; exit 1; }
 echo "tests: $(tail -n 1 gpurun_out/ab_gemm_tests.log)"
 python tools/gemm_bench.py > gpurun_out/ab_gemm_new.log 2>&1
 XM3D_LIB=$BASE python tools/gemm_bench.py > gpurun_out/ab_gemm_base.log 2>&1
