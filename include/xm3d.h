@@ -359,6 +359,15 @@ int xm3d_split_f16t_nhwc(const float* x, int64_t B, int64_t HW, int32_t C, const
 int xm3d_gemm_f32(const void* x_hi, const void* x_lo, int64_t M, int32_t K, int64_t ldx, const void* wp_hi, const void* wp_lo, int32_t N, const float* bias,
                   int32_t act, float alpha, const float* residual, int64_t ldr, float* out, int64_t ldo, int32_t waves, int32_t conv, int64_t B, int32_t Hin,
                   int32_t Win, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, void* stream);
+/* xm3d_gemm_f32 straight from the F32 activation (gemm.hip GF_XF32): x (M, K) f32 rows with row stride ldx floats (conv = 1: the channels-last
+ * f32 image) is split into its half planes x x_scale = hi + lo WHILE IT IS STAGED - no xm3d_split_f16t_nhwc pass in front, no half planes in
+ * memory; bit-identical to that pass followed by xm3d_gemm_f32.  x_scale: a power of two; |x| x_scale beyond 65504 raises the sticky range flag
+ * (xm3d_check_flag).  alpha = 1 / (x_scale t).  Replaces the frozen f32 Linear / Conv2d layers of ldm's UNet / VAE and open_clip's ViT in the
+ * reference's fp32 arithmetic (/root/reference/models/modeling/meta_arch/ldm.py:386-490, clip.py:239-270, run/train.py:178). */
+int xm3d_gemm_f32x(const float* x, float x_scale, int64_t M, int32_t K, int64_t ldx, const void* wp_hi, const void* wp_lo, int32_t N, const float* bias,
+                   int32_t act, float alpha, const float* residual, int64_t ldr, float* out, int64_t ldo, int32_t waves, int32_t conv, int64_t B,
+                   int32_t Hin, int32_t Win, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo,
+                   void* stream);
 /* GroupNorm moments alone, in the layout the calls above take: stats[0 .. B*G*2) f64 <- (sum, sum of squares) of x (+ shift) per
  * (sample, group); x (B, H*W, C) channels-last, dtype 0 = f32 / 1 = bf16; stats holds xm3d_gn_stats_doubles_nhwc doubles. */
 int xm3d_group_norm_nhwc_stats(const void* x, const void* shift, int32_t shift_bstride, int32_t dtype, int64_t B, int32_t C, int32_t hw,

@@ -89,3 +89,33 @@ def test_one_scale_split_flags_operands_beyond_the_half_range(dev):
     ops.gemm_f32_fused(x, packs, n, sw)
     torch.cuda.synchronize()
     assert lib().xm3d_check_flag() != 0 and lib().xm3d_check_flag() == 0
+
+
+def test_in_kernel_operand_split_equals_the_split_pass_bit_for_bit(dev, monkeypatch):
+    """xm3d_gemm_f32x (the f32 activation split into its half planes while it is staged) against xm3d_split_f16t_nhwc + xm3d_gemm_f32: the same
+    bits, GEMM (with epilogues) and convolution form (strided, zero padding, 1x1), incl. rows past M and inputs in the denormal-lo range"""
+    from xmask3d_amd import ops
+
+    g = torch.Generator().manual_seed(11)
+    for M, K, N, act, res in [(5140, 1024, 1024, "quick_gelu", False), (1000, 320, 960, None, True), (130, 64, 32, "gelu", True), (257, 2048, 256, "relu", False)]:
+        x = (torch.randn(M, K, generator=g) * torch.logspace(-6, 2, K).view(1, K)).to(dev)
+        w = (torch.randn(N, K, generator=g) / K ** 0.5).to(dev)
+        bias = torch.randn(N, generator=g).to(dev)
+        r = torch.randn(M, N, generator=g).to(dev) if res else None
+        packs, _, n, sw = ops.gemm_pack_weight_f16(w, one_scale=True)
+        monkeypatch.setattr(ops, "_F32_SPLIT_IN_KERNEL", True)
+        a = ops.gemm_f32_fused(x, packs, n, sw, bias=bias, act=act, residual=r)
+        monkeypatch.setattr(ops, "_F32_SPLIT_IN_KERNEL", False)
+        b = ops.gemm_f32_fused(x, packs, n, sw, bias=bias, act=act, residual=r)
+        assert torch.equal(a, b), (M, K, N, act, float((a - b).abs().max()))
+    for B, cin, H, W, cout, k, stride, pad in [(2, 128, 64, 64, 128, 3, 2, (0, 0, 1, 1)), (3, 1280, 8, 8, 1280, 3, 1, (1, 1, 1, 1)),
+                                               (2, 512, 32, 32, 512, 1, 1, (0, 0, 0, 0)), (2, 512, 16, 16, 8, 3, 1, (1, 1, 1, 1))]:
+        x = (torch.randn(B, cin, H, W, generator=g) * 1.5 + 0.3).to(dev).contiguous(memory_format=torch.channels_last)
+        w = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).to(dev)
+        packs, _, n32, sw = ops.gemm_pack_weight_f16(w, one_scale=True)
+        bpad = torch.randn(n32, generator=g).to(dev)
+        monkeypatch.setattr(ops, "_F32_SPLIT_IN_KERNEL", True)
+        a = ops.conv_gemm_f32_fused(x, packs, n32, sw, cout, k, stride, pad, bias=bpad)
+        monkeypatch.setattr(ops, "_F32_SPLIT_IN_KERNEL", False)
+        b = ops.conv_gemm_f32_fused(x, packs, n32, sw, cout, k, stride, pad, bias=bpad)
+        assert torch.equal(a, b), (B, cin, H, W, cout, k, stride)

@@ -85,6 +85,8 @@ _SIGS = {
     "xm3d_split_f16t_nhwc": (ctypes.c_int, [c_vp, c_i64, c_i64, c_i32, c_vp, c_vp, c_vp, c_vp, c_i32, ctypes.c_float, c_i32, c_i32, ctypes.c_float, c_vp, c_vp, c_vp, c_vp]),
     "xm3d_gemm_f32": (ctypes.c_int, [c_vp, c_vp, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp, c_i32, ctypes.c_float, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
                                      c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
+    "xm3d_gemm_f32x": (ctypes.c_int, [c_vp, ctypes.c_float, c_i64, c_i32, c_i64, c_vp, c_vp, c_i32, c_vp, c_i32, ctypes.c_float, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
+                                      c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "xm3d_gemm_f32acc": (ctypes.c_int, [c_vp, c_i64, c_i32, c_i64, c_vp, c_i32, c_i32, c_vp, c_i32, ctypes.c_float, c_vp, c_vp, c_i64, c_vp, c_i64, c_i32, c_i32,
                                         c_i64, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_i32, c_vp]),
     "xm3d_group_norm_nhwc_stats": (ctypes.c_int, [c_vp, c_vp, c_i32, c_i32, c_i64, c_i32, c_i32, c_i32, c_vp, c_vp]),

@@ -61,6 +61,8 @@ struct GemmArgs {
     int chunks_per_split;    // K chunks per blockIdx.y slice (split-K; = K / KC without)
     // GF_CONV: row m = output pixel (b, oy, ox) of a (ksz x ksz, stride, zero padding) convolution, K = ksz * ksz * Cin in (ky, kx, c) order
     int Hin, Win, Cin, Ho, Wo, stride, pad_t, pad_l, ksz;
+    float xscale = 1.f;      // GF_XF32: the power-of-two operand scale s of x
+    int* flag = nullptr;     // GF_XF32: sticky device flag, set when |x s| leaves the half range (xm3d_check_flag)
 };
 
 // FL bits.  GF_CONV: implicit-GEMM convolution - the token rows are gathered from the image while they are staged (no im2col tensor):
@@ -71,7 +73,10 @@ struct GemmArgs {
 // (wp, wp2) streamed, three MFMAs per k-step into ONE accumulator: x_hi w_lo + x_lo w_hi + x_hi w_hi.  Needs the small terms at their TRUE
 // scale (lo = half(x s - hi), not times 2^11): fine while |x s| >= 2^-3 keeps lo a normal half - smaller |x| lose only absolute precision
 // (2^-24 / s), which is invisible next to 1e-6 of max|out|.  A third of the token / output traffic of the three accumulating passes.
-enum { GF_CONV = 1, GF_OUT32 = 2, GF_F16 = 4, GF_SPLIT3 = 8 };
+// GF_XF32 (with GF_SPLIT3): x is the F32 tensor itself; a piece is 8 floats (two 16-byte loads) and is split into its two half planes
+// (hi = half(x s), lo = half(x s - hi): the arithmetic of k_split_nhwc, bit for bit) on its way into LDS - the separate split pass in front of
+// every f32-accurate GEMM (one read + one write of the activation, 9.9 % of the fp32 configuration's device time) is gone.
+enum { GF_CONV = 1, GF_OUT32 = 2, GF_F16 = 4, GF_SPLIT3 = 8, GF_XF32 = 16 };
 typedef _Float16 gm_f16x8 __attribute__((ext_vector_type(8)));
 
 // GELU(x) = x/2 (1 + erf(x / sqrt 2)) with erf from Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, two hardware transcendentals)
@@ -114,6 +119,8 @@ template <int CT, int ACT, int KC, int NW, int FL>
 __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     static_assert(NW == 8 || (NW == 4 && CT == 128), "geometries");
     constexpr bool CONV = (FL & GF_CONV) != 0, OUT32 = (FL & GF_OUT32) != 0, F16 = (FL & GF_F16) != 0, SP3 = (FL & GF_SPLIT3) != 0;
+    constexpr bool XF32 = (FL & GF_XF32) != 0;
+    static_assert(!XF32 || SP3, "f32 rows are split on the fly only in the one-launch form");
     static_assert(!OUT32 || ACT != GM_ACT_GEGLU, "GEGLU has no f32-output form");
     static_assert(!SP3 || (F16 && OUT32 && CT == 128 && KC == 64), "the one-launch split form: halves, f32 out, 128-column tiles, 64-channel chunks");
     constexpr int NPLN = SP3 ? 2 : 1;      // operand planes staged per buffer
@@ -220,8 +227,44 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
         } else {
             off = aoff[r] + (cfirst + (c < nch ? c : nch - 1)) * KC;
         }
-        raw[r] = *reinterpret_cast<const gm_u32x4*>(a.x + off);
-        if constexpr (SP3) raw2[r] = *reinterpret_cast<const gm_u32x4*>(a.x2 + off);
+        if constexpr (XF32) {  // 8 consecutive floats of the row
+            const float* const xf = reinterpret_cast<const float*>(a.x) + off;
+            raw[r] = *reinterpret_cast<const gm_u32x4*>(xf);
+            raw2[r] = *reinterpret_cast<const gm_u32x4*>(xf + 4);
+        } else {
+            raw[r] = *reinterpret_cast<const gm_u32x4*>(a.x + off);
+            if constexpr (SP3) raw2[r] = *reinterpret_cast<const gm_u32x4*>(a.x2 + off);
+        }
+    };
+    // GF_XF32: piece r (8 floats in raw / raw2) -> its two half planes.  t = x s is exact (s a power of two), hi = half(t) to nearest,
+    // t - hi is exact in f32, lo = half(t - hi): the values k_split_nhwc writes.  |t| beyond the half range raises the sticky flag.
+    bool xbad = false;
+    auto a_split = [&](int r, gm_u32x4& ph, gm_u32x4& pl) __attribute__((always_inline)) {
+        float tmax = 0.f;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const float t0 = __uint_as_float(j < 2 ? raw[r][2 * j] : raw2[r][2 * j - 4]) * a.xscale;
+            const float t1 = __uint_as_float(j < 2 ? raw[r][2 * j + 1] : raw2[r][2 * j - 3]) * a.xscale;
+            const _Float16 h0 = (_Float16)t0, h1 = (_Float16)t1;
+            const _Float16 l0 = (_Float16)(t0 - (float)h0), l1 = (_Float16)(t1 - (float)h1);
+            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+            ph[j] = __builtin_bit_cast(unsigned, h2{h0, h1});
+            pl[j] = __builtin_bit_cast(unsigned, h2{l0, l1});
+            tmax = fmaxf(tmax, fmaxf(fabsf(t0), fabsf(t1)));
+        }
+        xbad |= !(tmax <= 65504.f);  // also true for a NaN input
+    };
+    // both planes of piece r into the staging buffer at `dst` (plane 1 at + ASZ); GF_CONV: zero padding under a tap outside the image
+    auto a_store = [&](int r, char* dst) __attribute__((always_inline)) {
+        if constexpr (XF32) {
+            gm_u32x4 ph, pl;
+            a_split(r, ph, pl);
+            if constexpr (CONV) {
+                if ((vmask[r] & wr_need) != wr_need) ph = pl = gm_u32x4{0u, 0u, 0u, 0u};
+            }
+            *reinterpret_cast<gm_u32x4*>(dst) = ph;
+            *reinterpret_cast<gm_u32x4*>(dst + ASZ) = pl;
+        }
     };
     auto a_piece = [&](int r) __attribute__((always_inline)) -> gm_u32x4 {  // zero padding: a piece under a tap outside the image
         if constexpr (CONV) return (vmask[r] & wr_need) == wr_need ? raw[r] : gm_u32x4{0u, 0u, 0u, 0u};
@@ -248,8 +291,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     wr_need = ld.need;
 #pragma unroll
     for (int r = 0; r < KS; ++r) {
-        *reinterpret_cast<gm_u32x4*>(a_wr + r * RPR * PSTR) = a_piece(r);
-        if constexpr (SP3) *reinterpret_cast<gm_u32x4*>(a_wr + ASZ + r * RPR * PSTR) = a_piece2(r);
+        if constexpr (XF32) {
+            a_store(r, a_wr + r * RPR * PSTR);
+        } else {
+            *reinterpret_cast<gm_u32x4*>(a_wr + r * RPR * PSTR) = a_piece(r);
+            if constexpr (SP3) *reinterpret_cast<gm_u32x4*>(a_wr + ASZ + r * RPR * PSTR) = a_piece2(r);
+        }
     }
     if constexpr (CONV) {
         if (nch > 1) tap_next(ld);
@@ -288,8 +335,12 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
             if (ACTV && g + 1 < XS) x_load(g + 1, (g + 1) & 1);
             __builtin_amdgcn_sched_barrier(0);
             if (half == 0) {
-                *reinterpret_cast<gm_u32x4*>(anext + ks * RPR * PSTR) = a_piece(ks);
-                if constexpr (SP3) *reinterpret_cast<gm_u32x4*>(anext + ASZ + ks * RPR * PSTR) = a_piece2(ks);
+                if constexpr (XF32) {
+                    a_store(ks, anext + ks * RPR * PSTR);
+                } else {
+                    *reinterpret_cast<gm_u32x4*>(anext + ks * RPR * PSTR) = a_piece(ks);
+                    if constexpr (SP3) *reinterpret_cast<gm_u32x4*>(anext + ASZ + ks * RPR * PSTR) = a_piece2(ks);
+                }
                 a_load(ks, c + 2);
             }
             if (ACTV) {
@@ -338,6 +389,9 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
         if (c < nch) chunk(c, P0{}, std::false_type{});
     }
 
+    if constexpr (XF32) {
+        if (xbad && a.flag) *a.flag = XM3D_ERANGE;
+    }
     // ---- epilogue.  Accumulator register i of lane (token l31 of tile n, half h) = column 16 h + i of the wave's row block
     if constexpr (ACT == GM_ACT_GEGLU) {
         // rows 0 .. 15 of the block are value columns 16 gblk + i, rows 16 .. 31 their gate columns: half 0 holds values, half 1
@@ -730,8 +784,10 @@ extern "C" int xm3d_conv_gemm_bf16(const void* x, int64_t B, int32_t Hin, int32_
 static int gemm_f32acc_impl(const void* x, const void* x_lo, int64_t M, int32_t K, int64_t ldx, const void* wpacked, const void* wpacked_lo, int32_t N,
                            int32_t col_tile, const float* bias, int32_t act, float alpha, const float* accin, const float* residual, int64_t ldr, float* out,
                            int64_t ldo, int32_t waves, int32_t conv, int64_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t ksize, int32_t stride,
-                           int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, void* stream) {
+                           int32_t pad_t, int32_t pad_l, int32_t Ho, int32_t Wo, void* stream, float x_f32_scale = 0.f) {
     XM3D_REQUIRE(x && wpacked && out, "gemm_f32acc: null pointer");
+    const bool xf32 = x_f32_scale > 0.f;  // x is the f32 tensor, split while it is staged (GF_XF32)
+    if (xf32) x_lo = x;                   // (the one-launch form; there is no second plane in memory)
     const bool fused = x_lo != nullptr;
     XM3D_REQUIRE(!fused || (wpacked_lo && !accin && ((reinterpret_cast<uintptr_t>(x_lo) | reinterpret_cast<uintptr_t>(wpacked_lo)) & 15) == 0),
                  "gemm_f32: the one-launch form needs both planes of x and both weight images (16-byte aligned), and takes no accin");
@@ -774,6 +830,15 @@ static int gemm_f32acc_impl(const void* x, const void* x_lo, int64_t M, int32_t 
     a.nct = (N + tile - 1) / tile;
     hipStream_t s = as_stream(stream);
     constexpr int FG = GF_F16 | GF_OUT32, FC = GF_F16 | GF_OUT32 | GF_CONV;
+    if (xf32) {
+        constexpr int XG = FG | GF_SPLIT3 | GF_XF32, XC = FC | GF_SPLIT3 | GF_XF32;
+        a.xscale = x_f32_scale;
+        a.flag = device_flag();
+        if (conv) return launch_gemm<128, GM_ACT_NONE, XC>(a, waves, 1, s);
+        if (act == GM_ACT_GELU) return launch_gemm<128, GM_ACT_GELU, XG>(a, waves, 1, s);
+        if (act == GM_ACT_QUICK_GELU) return launch_gemm<128, GM_ACT_QUICK_GELU, XG>(a, waves, 1, s);
+        return launch_gemm<128, GM_ACT_NONE, XG>(a, waves, 1, s);
+    }
     if (fused) {
         constexpr int SG = FG | GF_SPLIT3, SC = FC | GF_SPLIT3;
         if (conv) return launch_gemm<128, GM_ACT_NONE, SC>(a, waves, 1, s);
@@ -811,4 +876,18 @@ extern "C" int xm3d_gemm_f32(const void* x_hi, const void* x_lo, int64_t M, int3
     XM3D_REQUIRE(x_lo && wp_lo, "gemm_f32: null pointer");
     return gemm_f32acc_impl(x_hi, x_lo, M, K, ldx, wp_hi, wp_lo, N, 128, bias, act, alpha, nullptr, residual, ldr, out, ldo, waves, conv, B, Hin, Win, Cin, ksize,
                             stride, pad_t, pad_l, Ho, Wo, stream);
+}
+
+// xm3d_gemm_f32 straight from the F32 activation: x (M, K) f32 rows (conv = 1: the channels-last f32 image) is split into its half planes
+// x x_scale = hi + lo while it is staged (GF_XF32) - no xm3d_split_f16t_nhwc pass, no half planes in memory; results are bit-identical to
+// that pass followed by xm3d_gemm_f32.  x_scale: a power of two; |x| x_scale beyond 65504 raises the sticky range flag (xm3d_check_flag).
+// alpha = 1 / (x_scale t) with t the weight scale of the packed images.  ldx in floats.
+extern "C" int xm3d_gemm_f32x(const float* x, float x_scale, int64_t M, int32_t K, int64_t ldx, const void* wp_hi, const void* wp_lo, int32_t N,
+                              const float* bias, int32_t act, float alpha, const float* residual, int64_t ldr, float* out, int64_t ldo, int32_t waves,
+                              int32_t conv, int64_t B, int32_t Hin, int32_t Win, int32_t Cin, int32_t ksize, int32_t stride, int32_t pad_t, int32_t pad_l,
+                              int32_t Ho, int32_t Wo, void* stream) {
+    XM3D_REQUIRE(wp_lo, "gemm_f32x: null pointer");
+    XM3D_REQUIRE(x_scale > 0.f, "gemm_f32x: x_scale must be a positive power of two");
+    return gemm_f32acc_impl(x, nullptr, M, K, ldx, wp_hi, wp_lo, N, 128, bias, act, alpha, nullptr, residual, ldr, out, ldo, waves, conv, B, Hin, Win, Cin, ksize,
+                            stride, pad_t, pad_l, Ho, Wo, stream, x_scale);
 }

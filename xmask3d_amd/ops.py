@@ -848,6 +848,11 @@ def _split_rows_f16t(x2):
     return hi, lo
 
 
+# the one-launch f32-accurate GEMM / convolution splits the f32 activation while it stages it (xm3d_gemm_f32x); XM3D_GEMM_F32_SPLIT=pass restores
+# the separate split pass (xm3d_split_f16t_nhwc + xm3d_gemm_f32: the same bits) for A/B timing
+_F32_SPLIT_IN_KERNEL = _os.environ.get("XM3D_GEMM_F32_SPLIT", "kernel") != "pass"
+
+
 def gemm_f32_fused(x, packs, n, sw, bias=None, act=None, residual=None):
     """gemm_f32 in ONE launch (xm3d_gemm_f32): packs, sw = gemm_pack_weight_f16(W, one_scale=True)[0, 3].  A third of the traffic of the three
     accumulating passes; activations beyond |x| = 4094 raise the sticky range flag."""
@@ -858,7 +863,6 @@ def gemm_f32_fused(x, packs, n, sw, bias=None, act=None, residual=None):
     if not x2.is_contiguous():
         x2 = x2.contiguous()
     m = x2.shape[0]
-    hi, lo = _split_rows_f16t(x2)
     out = torch.empty(x.shape[:-1] + (n,), dtype=torch.float32, device=x.device)
     ldr = 0
     if residual is not None:
@@ -867,6 +871,11 @@ def gemm_f32_fused(x, packs, n, sw, bias=None, act=None, residual=None):
         ldr = n
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != n):
         raise TypeError("gemm_f32_fused: bias must be a contiguous f32 (n,) tensor")
+    if _F32_SPLIT_IN_KERNEL and x2.data_ptr() % 16 == 0:
+        check(lib().xm3d_gemm_f32x(_ptr(x2), F16T_X_SCALE, m, k, k, _ptr(packs[0]), _ptr(packs[1]), n, _ptr(bias), GEMM_ACTS[act], 1.0 / (F16T_X_SCALE * sw),
+                                   _ptr(residual), ldr, _ptr(out), n, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, _stream()), "xm3d_gemm_f32x")
+        return out
+    hi, lo = _split_rows_f16t(x2)
     check(lib().xm3d_gemm_f32(_ptr(hi), _ptr(lo), m, k, k, _ptr(packs[0]), _ptr(packs[1]), n, _ptr(bias), GEMM_ACTS[act], 1.0 / (F16T_X_SCALE * sw),
                               _ptr(residual), ldr, _ptr(out), n, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, _stream()), "xm3d_gemm_f32")
     return out
@@ -879,10 +888,6 @@ def conv_gemm_f32_fused(x, packs, n32, sw, cout, ksize, stride=1, padding=(0, 0,
     B, cin, H, W = x.shape
     pt, pl, pb, pr = (int(p) for p in padding)
     Ho, Wo = (H + pt + pb - ksize) // stride + 1, (W + pl + pr - ksize) // stride + 1
-    hi = torch.empty((B, cin, H, W), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
-    lo = torch.empty_like(hi)
-    check(lib().xm3d_split_f16t_nhwc(_ptr(x), B, H * W, cin, None, None, None, None, 0, 0.0, 0, 0, F16T_X_SCALE, _ptr(hi), _ptr(lo), None, _stream()),
-          "xm3d_split_f16t_nhwc")
     out = torch.empty((B, Ho, Wo, n32), dtype=torch.float32, device=x.device)
     ldr = 0
     if residual is not None:
@@ -891,9 +896,18 @@ def conv_gemm_f32_fused(x, packs, n32, sw, cout, ksize, stride=1, padding=(0, 0,
         ldr = n32
     if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous() or bias.numel() != n32):
         raise TypeError("conv_gemm_f32_fused: bias must be a contiguous f32 (padded cout,) tensor")
-    check(lib().xm3d_gemm_f32(_ptr(hi), _ptr(lo), B * Ho * Wo, ksize * ksize * cin, 0, _ptr(packs[0]), _ptr(packs[1]), n32, _ptr(bias), 0,
-                              1.0 / (F16T_X_SCALE * sw), _ptr(residual), ldr, _ptr(out), n32, 0, 1, B, H, W, cin, ksize, stride, pt, pl, Ho, Wo, _stream()),
-          "xm3d_gemm_f32")
+    if _F32_SPLIT_IN_KERNEL and x.data_ptr() % 16 == 0:
+        check(lib().xm3d_gemm_f32x(_ptr(x), F16T_X_SCALE, B * Ho * Wo, ksize * ksize * cin, 0, _ptr(packs[0]), _ptr(packs[1]), n32, _ptr(bias), 0,
+                                   1.0 / (F16T_X_SCALE * sw), _ptr(residual), ldr, _ptr(out), n32, 0, 1, B, H, W, cin, ksize, stride, pt, pl, Ho, Wo,
+                                   _stream()), "xm3d_gemm_f32x")
+    else:
+        hi = torch.empty((B, cin, H, W), dtype=torch.float16, device=x.device, memory_format=torch.channels_last)
+        lo = torch.empty_like(hi)
+        check(lib().xm3d_split_f16t_nhwc(_ptr(x), B, H * W, cin, None, None, None, None, 0, 0.0, 0, 0, F16T_X_SCALE, _ptr(hi), _ptr(lo), None, _stream()),
+              "xm3d_split_f16t_nhwc")
+        check(lib().xm3d_gemm_f32(_ptr(hi), _ptr(lo), B * Ho * Wo, ksize * ksize * cin, 0, _ptr(packs[0]), _ptr(packs[1]), n32, _ptr(bias), 0,
+                                  1.0 / (F16T_X_SCALE * sw), _ptr(residual), ldr, _ptr(out), n32, 0, 1, B, H, W, cin, ksize, stride, pt, pl, Ho, Wo, _stream()),
+              "xm3d_gemm_f32")
     img = out.permute(0, 3, 1, 2)
     return img if n32 == cout else img[:, :cout].contiguous(memory_format=torch.channels_last)
 
