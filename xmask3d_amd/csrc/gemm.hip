@@ -240,17 +240,20 @@ __global__ __launch_bounds__(NW * 64) void k_gemm(const GemmArgs a) {
     // t - hi is exact in f32, lo = half(t - hi): the values k_split_nhwc writes.  |t| beyond the half range raises the sticky flag.
     bool xbad = false;
     auto a_split = [&](int r, gm_u32x4& ph, gm_u32x4& pl) __attribute__((always_inline)) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        typedef _Float16 h2 __attribute__((ext_vector_type(2)));
+        const f2 s2 = {a.xscale, a.xscale};
         float tmax = 0.f;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const float t0 = __uint_as_float(j < 2 ? raw[r][2 * j] : raw2[r][2 * j - 4]) * a.xscale;
-            const float t1 = __uint_as_float(j < 2 ? raw[r][2 * j + 1] : raw2[r][2 * j - 3]) * a.xscale;
-            const _Float16 h0 = (_Float16)t0, h1 = (_Float16)t1;
-            const _Float16 l0 = (_Float16)(t0 - (float)h0), l1 = (_Float16)(t1 - (float)h1);
-            typedef _Float16 h2 __attribute__((ext_vector_type(2)));
-            ph[j] = __builtin_bit_cast(unsigned, h2{h0, h1});
-            pl[j] = __builtin_bit_cast(unsigned, h2{l0, l1});
-            tmax = fmaxf(tmax, fmaxf(fabsf(t0), fabsf(t1)));
+        for (int j = 0; j < 4; ++j) {  // pairs on the packed pipe: v_pk_mul_f32, v_cvt_pk_f16_f32, v_pk_add_f32
+            const f2 x2 = {__uint_as_float(j < 2 ? raw[r][2 * j] : raw2[r][2 * j - 4]), __uint_as_float(j < 2 ? raw[r][2 * j + 1] : raw2[r][2 * j - 3])};
+            const f2 t2 = x2 * s2;
+            const h2 hh = __builtin_convertvector(t2, h2);
+            const f2 d2 = t2 - __builtin_convertvector(hh, f2);
+            const h2 ll = __builtin_convertvector(d2, h2);
+            ph[j] = __builtin_bit_cast(unsigned, hh);
+            pl[j] = __builtin_bit_cast(unsigned, ll);
+            tmax = fmaxf(tmax, fmaxf(fabsf(t2[0]), fabsf(t2[1])));
         }
         xbad |= !(tmax <= 65504.f);  // also true for a NaN input
     };
