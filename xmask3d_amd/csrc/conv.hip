@@ -464,56 +464,76 @@ __global__ __launch_bounds__(NW * 64, 2) void k_conv3x3_f32acc(const ConvArgs a)
 }
 
 // f32 (B, H*W, C) -> bf16 hi / lo with x = hi + lo (+ <= 2^-17 |x|), optionally through y = act(x * scale + shift) with the
-// per-(image, channel) GroupNorm affine of k_gn_affine: the operand split of the f32-accurate convolution.  One thread = 8 channels.
+// per-(image, channel) GroupNorm affine of k_gn_affine: the operand split of the f32-accurate convolution.
 // f16 (scale_hi > 0): hi = half(y * scale_hi), lo = half((y - hi / scale_hi) * scale_hi * 2^11): y = hi / s + lo / (s 2^11) to 2^-22 |y|; both terms
 // live at the magnitude of y * s, so neither loses bits to the half's narrow exponent range; values beyond 65504 / s set the range flag
-__global__ void k_split_nhwc(const float* __restrict__ x, const float* __restrict__ affine, int act, int64_t n8, int C, int64_t hw,
-                             __bf16* __restrict__ hi, __bf16* __restrict__ lo, __bf16* __restrict__ lo2, float scale_hi, float lo_mul,
-                             int* __restrict__ flag) {
-    const int64_t i = int64_t(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i >= n8) return;
-    const int c8 = C / 8;
-    const int c = int(i % c8);
-    const int64_t b = i / c8 / hw;
-    const float4 v0 = *reinterpret_cast<const float4*>(x + i * 8), v1 = *reinterpret_cast<const float4*>(x + i * 8 + 4);
-    float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
-    if (affine) {
-        const float* t = affine + (b * C + c * 8) * 2;
+// Mapping: a thread owns TWO groups of 4 consecutive channels, float4 index q and q + 256 of its image (blockIdx.y): every load / store
+// instruction of a wave is one contiguous run (lane stride 16 bytes in, 8 bytes out).  (One thread = 8 consecutive channels made each 16-byte
+// load a 32-byte-strided gather and spent two 64-bit divisions per thread on the indices: 2.2 TB/s.)  One 32-bit remainder per thread.
+__global__ __launch_bounds__(256) void k_split_nhwc(const float* __restrict__ x, const float* __restrict__ affine, int act, unsigned per_img4, int C,
+                                                    __bf16* __restrict__ hi, __bf16* __restrict__ lo, __bf16* __restrict__ lo2, float scale_hi,
+                                                    float lo_mul, int* __restrict__ flag) {
+    typedef _Float16 cv_f16x4 __attribute__((ext_vector_type(4)));
+    const unsigned cg = unsigned(C) >> 2;  // float4 groups per pixel
+    const int b = blockIdx.y;
+    const unsigned q0 = blockIdx.x * 512u + threadIdx.x;
+    const int64_t ibase = int64_t(b) * per_img4 * 4;
+    unsigned c4 = q0 % cg;
+    const unsigned step = 256u % cg;
+    float4 vin[2];
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            float y = fmaf(v[j], t[j], t[8 + j]);
-            if (act == 1) y = y / (1.f + expf(-y));
-            else if (act == 2) y = fmaxf(y, 0.f);
-            v[j] = y;
+    for (int u = 0; u < 2; ++u) {
+        const unsigned q = q0 + 256u * u;
+        vin[u] = q < per_img4 ? *reinterpret_cast<const float4*>(x + ibase + int64_t(q) * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    bool bad = false;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const unsigned q = q0 + 256u * u;
+        const int c = int(c4) * 4;  // first of this group's 4 channels
+        c4 += step;
+        if (c4 >= cg) c4 -= cg;
+        if (q >= per_img4) continue;
+        const int64_t e = ibase + int64_t(q) * 4;
+        float v[4] = {vin[u].x, vin[u].y, vin[u].z, vin[u].w};
+        if (affine) {
+            const float* t = affine + (int64_t(b) * C + (c & ~7)) * 2 + (c & 7);  // [8 scales][8 shifts] per 8-channel block (k_gn_affine)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float y = fmaf(v[j], t[j], t[8 + j]);
+                // SiLU on the two hardware transcendentals (v_exp_f32, v_rcp_f32: ~1 ulp each) like the bf16 kernel's staging
+                if (act == 1) y = y * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-CV_LOG2E * y));
+                else if (act == 2) y = fmaxf(y, 0.f);
+                v[j] = y;
+            }
+        }
+        if (scale_hi > 0.f) {
+            cv_f16x4 h4, l4;
+            const float inv = 1.f / scale_hi, sl = scale_hi * lo_mul;  // powers of two: exact (lo_mul 2048: the scaled small term; 1: at hi's scale)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = v[j] * scale_hi;
+                bad |= !(fabsf(t) <= 65504.f);
+                h4[j] = (_Float16)t;
+                l4[j] = (_Float16)((v[j] - float(h4[j]) * inv) * sl);
+            }
+            *reinterpret_cast<cv_f16x4*>(hi + e) = h4;
+            *reinterpret_cast<cv_f16x4*>(lo + e) = l4;
+        } else {
+            cv_bf16x4 h4, l4, m4;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                h4[j] = (__bf16)v[j];
+                const float r1 = v[j] - float(h4[j]);  // exact in f32
+                l4[j] = (__bf16)r1;
+                m4[j] = (__bf16)(r1 - float(l4[j]));   // third term: x = hi + lo + lo2 to 2^-25 |x|
+            }
+            *reinterpret_cast<cv_bf16x4*>(hi + e) = h4;
+            *reinterpret_cast<cv_bf16x4*>(lo + e) = l4;
+            if (lo2) *reinterpret_cast<cv_bf16x4*>(lo2 + e) = m4;
         }
     }
-    if (scale_hi > 0.f) {
-        cv_f16x8 h8, l8;
-        const float inv = 1.f / scale_hi, sl = scale_hi * lo_mul;  // powers of two: exact (lo_mul 2048: the scaled small term; 1: at hi's scale)
-        bool bad = false;
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const float t = v[j] * scale_hi;
-            bad |= !(fabsf(t) <= 65504.f);
-            h8[j] = (_Float16)t;
-            l8[j] = (_Float16)((v[j] - float(h8[j]) * inv) * sl);
-        }
-        if (bad) *flag = XM3D_ERANGE;
-        *reinterpret_cast<cv_f16x8*>(hi + i * 8) = h8;
-        *reinterpret_cast<cv_f16x8*>(lo + i * 8) = l8;
-        return;
-    }
-    cv_bf16x8 h8, l8, m8;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-        h8[j] = (__bf16)v[j];
-        const float r1 = v[j] - float(h8[j]);  // exact in f32
-        l8[j] = (__bf16)r1;
-        m8[j] = (__bf16)(r1 - float(l8[j]));   // third term: x = hi + lo + lo2 to 2^-25 |x|
-    }
-    *reinterpret_cast<cv_bf16x8*>(hi + i * 8) = h8;
-    *reinterpret_cast<cv_bf16x8*>(lo + i * 8) = l8;
-    if (lo2) *reinterpret_cast<cv_bf16x8*>(lo2 + i * 8) = m8;
+    if (bad) *flag = XM3D_ERANGE;
 }
 
 // OHWI (cout, 9, cin) bf16 -> fragment-ordered weight streams [cout tile][32-row block][chunk][tap][k-step][lane][8]: lane l of
@@ -750,9 +770,10 @@ static int split_nhwc_impl(const float* x, int64_t B, int64_t HW, int32_t C, con
     } else {
         XM3D_REQUIRE(act == 0 && !in_shift, "split_bf16_nhwc: activation / shift need the GroupNorm statistics");
     }
-    const int64_t n8 = B * HW * (C / 8);
-    hipLaunchKernelGGL(k_split_nhwc, dim3(unsigned((n8 + 255) / 256)), dim3(256), 0, s, x, affine, act, n8, C, HW, static_cast<__bf16*>(hi),
-                       static_cast<__bf16*>(lo), static_cast<__bf16*>(lo2), scale_hi, lo_mul, device_flag());
+    const int64_t per_img4 = HW * (C / 4);  // float4 groups per image
+    XM3D_REQUIRE(per_img4 < (int64_t(1) << 31) && B <= 65535, "split_bf16_nhwc: image of %lld x %d elements / batch %lld too large", (long long)HW, C, (long long)B);
+    hipLaunchKernelGGL(k_split_nhwc, dim3(unsigned((per_img4 + 511) / 512), unsigned(B)), dim3(256), 0, s, x, affine, act, unsigned(per_img4), C,
+                       static_cast<__bf16*>(hi), static_cast<__bf16*>(lo), static_cast<__bf16*>(lo2), scale_hi, lo_mul, device_flag());
     XM3D_LAUNCH_CHECK();
     return XM3D_OK;
 }
