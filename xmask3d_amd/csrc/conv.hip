@@ -497,10 +497,14 @@ __global__ __launch_bounds__(256) void k_split_nhwc(const float* __restrict__ x,
         const int64_t e = ibase + int64_t(q) * 4;
         float v[4] = {vin[u].x, vin[u].y, vin[u].z, vin[u].w};
         if (affine) {
-            const float* t = affine + (int64_t(b) * C + (c & ~7)) * 2 + (c & 7);  // [8 scales][8 shifts] per 8-channel block (k_gn_affine)
+            // [8 scales][8 shifts] per 8-channel block (k_gn_affine); c & 7 is 0 or 4: two aligned 16-byte loads, not eight 4-byte ones (the
+            // table loads, not the data, were most of this pass's vector-memory instructions)
+            const float* t = affine + (int64_t(b) * C + (c & ~7)) * 2 + (c & 7);
+            const float4 sc4 = *reinterpret_cast<const float4*>(t), sh4 = *reinterpret_cast<const float4*>(t + 8);
+            const float scj[4] = {sc4.x, sc4.y, sc4.z, sc4.w}, shj[4] = {sh4.x, sh4.y, sh4.z, sh4.w};
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                float y = fmaf(v[j], t[j], t[8 + j]);
+                float y = fmaf(v[j], scj[j], shj[j]);
                 // SiLU on the two hardware transcendentals (v_exp_f32, v_rcp_f32: ~1 ulp each) like the bf16 kernel's staging
                 if (act == 1) y = y * __builtin_amdgcn_rcpf(1.f + __builtin_amdgcn_exp2f(-CV_LOG2E * y));
                 else if (act == 2) y = fmaxf(y, 0.f);
@@ -763,6 +767,7 @@ static int split_nhwc_impl(const float* x, int64_t B, int64_t HW, int32_t C, con
     if (gn_stats) {
         XM3D_REQUIRE(gamma && beta && groups > 0 && C % groups == 0 && ws && (act == 0 || act == 1 || act == 2), "split_bf16_nhwc: bad GroupNorm arguments");
         XM3D_REQUIRE(in_shift_bstride == 0 || in_shift_bstride == C, "split_bf16_nhwc: in_shift_bstride must be 0 or C");
+        XM3D_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, "split_bf16_nhwc: the affine workspace must be 16-byte aligned");
         const int n = int(B) * C;
         hipLaunchKernelGGL(k_gn_affine, dim3((n + 255) / 256), dim3(256), 0, s, gn_stats, gamma, beta, in_shift, in_shift_bstride, int(B), C, groups,
                            1.0 / (double(HW) * (C / groups)), eps, static_cast<float*>(ws));
