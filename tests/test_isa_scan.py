@@ -53,3 +53,10 @@ def test_inference_kernels_do_not_spill(kernels):
     """scratch traffic only in the 160-channel attention backward (512 registers, training in bf16) and the GEMM's loop-invariant pair"""
     bad = {k: c["scratch"] for k, c in kernels.items() if c["scratch"] > 8 and not k.startswith("k_attn_bwd")}
     assert not bad, bad
+
+
+def test_split_pass_reads_its_groupnorm_table_as_vectors(kernels):
+    """k_split_nhwc was vector-memory-INSTRUCTION bound (2.2 TB/s) while it read the per-channel scale / shift table with eight 4-byte loads
+    per 4-channel group; with two 16-byte loads it streams at 5.9 TB/s (profiles/r04_split_pass_bench.log)"""
+    c = kernels["k_split_nhwc"]
+    assert c["narrow_loads"] == 0 and c["wide_loads"] >= 4, dict(c)

@@ -1,5 +1,6 @@
 """Static scan of the device code inside libxm3d_hip.so: per kernel the instruction count, AGPR copies (v_accvgpr_*), compare / select
-cascades (v_cmp_eq_u32: hipcc's lowering of a vector extract with a run-time index) and scratch accesses (register spills).  This is how
+cascades (v_cmp_eq_u32: hipcc's lowering of a vector extract with a run-time index), scratch accesses (register spills) and narrow (<= 4-byte)
+against wide global loads.  This is how
 the round-4 attention and GEGLU findings were made; tests/test_isa_scan.py keeps them fixed.
 usage: python tools/isa_scan.py [path/to/libxm3d_hip.so]"""
 import collections
@@ -63,6 +64,12 @@ def scan(so_path=None):
                     cur["scratch"] += 1
                 elif "v_mfma" in line:
                     cur["mfma"] += 1
+                else:
+                    op = line.split()[0]
+                    if op in ("global_load_dword", "global_load_ushort", "global_load_ubyte", "global_load_sshort", "global_load_short_d16"):
+                        cur["narrow_loads"] += 1  # <= 4 bytes per lane
+                    elif op.startswith("global_load_dwordx"):
+                        cur["wide_loads"] += 1
     return res
 
 
